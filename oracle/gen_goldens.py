@@ -1,0 +1,351 @@
+"""Generate golden vectors for the hot path from the *imported reference*.
+
+Runs ONLY in the build container (the reference never travels):
+
+    cd /tmp && PYTHONPATH=/root/reference /opt/conda/bin/python3.9 -W ignore \
+        /root/repo/oracle/gen_goldens.py /root/repo/tests/golden
+
+It imports ``scl`` (reference), encodes/decodes seeded inputs with the reference's own
+Encoder/Decoder classes and stores *data only*: parameters, input symbol indices, the packed
+output bits, their length, and ``num_bits_consumed`` for 0 / 3 / 61 stored trailing garbage bits.
+The fixtures pin oracle/scl_oracle.c (tests/test_oracle_goldens.py) and, through it and directly,
+the HIP kernels (tests/test_gpu_goldens.py).  Groups follow SURVEY.md section 8c (G1..G8).
+"""
+import copy
+import json
+import sys
+
+import numpy as np
+
+from scl.compressors.arithmetic_coding import AECParams, ArithmeticDecoder, ArithmeticEncoder
+from scl.compressors.probability_models import (
+    AdaptiveIIDFreqModel,
+    AdaptiveOrderKFreqModel,
+    FixedFreqModel,
+)
+from scl.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from scl.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from scl.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from scl.core.data_block import DataBlock
+from scl.core.prob_dist import Frequencies
+from scl.utils.bitarray_utils import BitArray
+from scl.utils.test_utils import get_random_data_block
+
+GARBAGE = (0, 3, 61)
+
+
+def t256_table():
+    """S2 frequency table of SURVEY.md 8d: 256 symbols, M = 4096, every f >= 1."""
+    w = np.random.default_rng(1).dirichlet(np.ones(256))
+    f = np.maximum(1, np.floor(4096 * w)).astype(np.int64)
+    f[int(np.argmax(f))] += 4096 - int(f.sum())
+    assert f.sum() == 4096 and f.min() >= 1
+    return f
+
+
+def pack(bits: BitArray):
+    return np.frombuffer(bits.tobytes(), dtype=np.uint8).copy(), len(bits)
+
+
+class Collector:
+    def __init__(self):
+        self.cases = []
+        self.arrays = {}
+
+    def add(self, meta, **arrays):
+        idx = len(self.cases)
+        meta = dict(meta)
+        meta["id"] = idx
+        self.cases.append(meta)
+        for k, v in arrays.items():
+            self.arrays[f"c{idx}_{k}"] = np.asarray(v)
+
+    def save(self, path):
+        np.savez_compressed(path, manifest=np.array(json.dumps(self.cases)), **self.arrays)
+        print(f"{path}: {len(self.cases)} cases")
+
+
+def trailing_checks(make_decoder, enc_bits, rng, expect_syms, alphabet):
+    """decode with 0/3/61 stored garbage bits appended; return garbage arrays + consumed counts."""
+    garb, consumed = [], []
+    for g in GARBAGE:
+        extra = rng.integers(0, 2, g).astype(np.uint8)
+        bits = BitArray(enc_bits)
+        bits.extend("".join(str(int(b)) for b in extra))
+        block, used = make_decoder().decode_block(bits)
+        assert [alphabet.index(s) for s in block.data_list] == list(expect_syms), "reference round trip failed"
+        assert used == len(enc_bits)
+        garb.append(extra)
+        consumed.append(used)
+    return garb, consumed
+
+
+def add_coder_case(col, kind, meta, alphabet, idx_syms, make_encoder, make_decoder, rng, decode=True):
+    data = DataBlock([alphabet[i] for i in idx_syms])
+    enc_bits = make_encoder().encode_block(data)
+    packed, nbits = pack(enc_bits)
+    arrays = dict(sym=np.asarray(idx_syms, dtype=np.uint8), out=packed)
+    meta = dict(meta, kind=kind, n=len(idx_syms), nbits=nbits)
+    if decode:
+        garb, consumed = trailing_checks(make_decoder, enc_bits, rng, idx_syms, alphabet)
+        meta["consumed"] = consumed
+        meta["garbage_lens"] = list(GARBAGE)
+        for g, arr in zip(GARBAGE, garb):
+            arrays[f"garbage{g}"] = arr
+    col.add(meta, **arrays)
+    return enc_bits
+
+
+def iid_indices(freq_list, n, seed):
+    p = np.asarray(freq_list, dtype=np.float64)
+    p = p / p.sum()
+    return np.random.default_rng(seed).choice(len(freq_list), size=n, p=p).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_rans(col, rng):
+    # G1: the reference's own known-answer test (rANS.py:303-360)
+    fr = Frequencies({"A": 3, "B": 3, "C": 2})
+    p = rANSParams(fr, DATA_BLOCK_SIZE_BITS=5, NUM_BITS_OUT=1, RANGE_FACTOR=1)
+    bits = add_coder_case(col, "rans", dict(group="G1", freq=[3, 3, 2], RF=1, b=1, size_bits=5), ["A", "B", "C"],
+                          [0, 2, 1], lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+    assert bits == BitArray("00011101110010")
+
+    # G3: the reference's parameter sweep (rANS.py:366-379) at several lengths incl. empty
+    sweep = [
+        ([1, 1, 2], {}),
+        ([12, 34, 1, 45], {}),
+        ([34, 35, 546, 1, 13, 245], dict(NUM_BITS_OUT=8)),
+        ([5, 5, 5, 5, 5, 5], dict(RANGE_FACTOR=1 << 12)),
+        ([1, 3], dict(RANGE_FACTOR=1 << 4)),
+    ]
+    for fl, kw in sweep:
+        alphabet = list("ABCDEF"[: len(fl)])
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        p = rANSParams(fr, **kw)
+        for n in (0, 1, 2, 17, 1000):
+            syms = iid_indices(fl, n, seed=0)
+            add_coder_case(col, "rans", dict(group="G3", freq=fl, RF=p.RANGE_FACTOR, b=p.NUM_BITS_OUT,
+                                             size_bits=p.DATA_BLOCK_SIZE_BITS), alphabet, syms,
+                           lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+
+    # G3b: K = 256, M = 4096 (the headline model) at several (b, RF)
+    f256 = t256_table().tolist()
+    alphabet = list(range(256))
+    fr = Frequencies(dict(zip(alphabet, f256)))
+    for b, RF, n in ((1, 1 << 16, 4096), (8, 1 << 8, 2048), (16, 1, 1024), (1, 1, 1024), (3, 1 << 5, 512)):
+        p = rANSParams(fr, NUM_BITS_OUT=b, RANGE_FACTOR=RF)
+        syms = iid_indices(f256, n, seed=2)
+        add_coder_case(col, "rans", dict(group="G3b", freq=f256, RF=RF, b=b, size_bits=32), alphabet, syms,
+                       lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+
+    # G3c: uniform 256-symbol table (f = 16, M = 4096), default params
+    fu = [16] * 256
+    fr = Frequencies(dict(zip(alphabet, fu)))
+    p = rANSParams(fr)
+    syms = np.random.default_rng(3).integers(0, 256, 2048, dtype=np.uint8)
+    add_coder_case(col, "rans", dict(group="G3c", freq=fu, RF=p.RANGE_FACTOR, b=1, size_bits=32), alphabet, syms,
+                   lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+
+    # G4: BASELINE.json configs[0] -- 4 KiB Bernoulli(0.8) block, default params
+    fr = Frequencies({0: 1, 1: 4})
+    p = rANSParams(fr)
+    block = get_random_data_block(fr.get_prob_dist(), 4096, seed=0)
+    bits = add_coder_case(col, "rans", dict(group="G4", freq=[1, 4], RF=p.RANGE_FACTOR, b=1, size_bits=32), [0, 1],
+                          np.asarray(block.data_list, dtype=np.uint8), lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+    assert len(bits) == 3068
+
+
+def gen_tans(col, rng):
+    # G2: lookup tables of the reference's KAT model (tANS.py:285-337) + its bitstream (:340-415)
+    fl = [3, 3, 2]
+    alphabet = ["A", "B", "C"]
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    p = tANSParams(fr, RANGE_FACTOR=1, NUM_BITS_OUT=1, DATA_BLOCK_SIZE_BITS=5)
+    enc, dec = tANSEncoder(p), tANSDecoder(p)
+    enc_tab = np.array([[alphabet.index(s), xs, v] for (s, xs), v in enc.base_encode_step_table.items()], dtype=np.int64)
+    dec_tab = np.array([[x, alphabet.index(s), xs] for x, (s, xs) in dec.base_decode_step_table.items()], dtype=np.int64)
+    nb_tab = np.array([enc.shrink_state_num_out_bits_base_table[s] for s in alphabet], dtype=np.int64)
+    th_tab = np.array([enc.shrink_state_thresh_table[s] for s in alphabet], dtype=np.int64)
+    ex_tab = np.array(sorted(dec.expand_state_num_bits_table.items()), dtype=np.int64)
+    col.add(dict(kind="tans_tables", group="G2", freq=fl, RF=1), enc_tab=enc_tab, dec_tab=dec_tab, nbits_tab=nb_tab,
+            thresh_tab=th_tab, expand_tab=ex_tab)
+    bits = add_coder_case(col, "tans", dict(group="G2", freq=fl, RF=1, size_bits=5), alphabet, [0, 2, 1],
+                          lambda: tANSEncoder(p), lambda: tANSDecoder(p), rng)
+    assert bits == BitArray("00011101110010")
+
+    # G5: the reference's tANS sweep (tANS.py:421-430; the third set uses RF=2^8 / 2^10 instead of the
+    # default 2^16, whose 2^20-entry tables take minutes to build in the reference)
+    sweep = [([1, 1, 2], 1), ([1, 3], 1 << 4), ([3, 4, 9], 1 << 8), ([3, 4, 9], 1 << 10)]
+    for fl, RF in sweep:
+        alphabet = list("ABCDEF"[: len(fl)])
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        p = tANSParams(fr, RANGE_FACTOR=RF)
+        enc_obj, dec_obj = tANSEncoder(p), tANSDecoder(p)
+        for n in (0, 1, 17, 1000):
+            syms = iid_indices(fl, n, seed=0)
+            add_coder_case(col, "tans", dict(group="G5", freq=fl, RF=p.RANGE_FACTOR, size_bits=32), alphabet, syms,
+                           lambda: enc_obj, lambda: dec_obj, rng)
+
+    # G5b: K = 256, M = 4096, RF = 1 and RF = 16; the stream must equal rANS with equal params
+    f256 = t256_table().tolist()
+    alphabet = list(range(256))
+    fr = Frequencies(dict(zip(alphabet, f256)))
+    for RF, n in ((1, 4096), (16, 1024)):
+        p = tANSParams(fr, RANGE_FACTOR=RF)
+        enc_obj, dec_obj = tANSEncoder(p), tANSDecoder(p)
+        syms = iid_indices(f256, n, seed=2)
+        bits = add_coder_case(col, "tans", dict(group="G5b", freq=f256, RF=RF, size_bits=32), alphabet, syms,
+                              lambda: enc_obj, lambda: dec_obj, rng)
+        rp = rANSParams(fr, RANGE_FACTOR=RF)
+        assert bits == rANSEncoder(rp).encode_block(DataBlock(syms.tolist()))
+
+
+def gen_range(col, rng):
+    # G6: reference sweep (range_coder.py:336-341) + edge cases (:351-374) + K=256 uniform
+    sweep = [[1, 1, 2], [12, 34, 1, 45], [34, 35, 546, 1, 13, 245], [5, 5, 5, 5, 5, 5], [1, 3], [1, 65534]]
+    for fl in sweep:
+        alphabet = list("ABCDEF"[: len(fl)])
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        p = RangeCoderParams()
+        syms = iid_indices(fl, 1000, seed=0)
+        add_coder_case(col, "range", dict(group="G6", freq=fl, precision=32, size_bits=32), alphabet, syms,
+                       lambda: RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), rng)
+    p = RangeCoderParams()
+    edge = [([1, 65535], [0, 1] * 500), ([1, 1, 65534], [0, 1, 2] * 300), ([1, 1, 65534], [0] * 700),
+            ([1, 1, 65534], [2] * 700), ([1, 1, 65534], [1] * 33)]
+    for fl, pattern in edge:
+        alphabet = list("ABC"[: len(fl)])
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        add_coder_case(col, "range", dict(group="G6edge", freq=fl, precision=32, size_bits=32), alphabet,
+                       pattern, lambda: RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), rng)
+    # every length 0..49 (flush correctness, empty block; range_coder.py:369-374)
+    fl = [12, 34, 1, 45]
+    alphabet = list("ABCD")
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    base = iid_indices(fl, 5000, seed=0)
+    for n in range(0, 50):
+        add_coder_case(col, "range", dict(group="G6len", freq=fl, precision=32, size_bits=32), alphabet,
+                       base[:n], lambda: RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), rng)
+    fu = [1] * 256
+    alphabet = list(range(256))
+    fr = Frequencies(dict(zip(alphabet, fu)))
+    p = RangeCoderParams()
+    syms = np.random.default_rng(3).integers(0, 256, 4096, dtype=np.uint8)
+    bits = add_coder_case(col, "range", dict(group="G6u", freq=fu, precision=32, size_bits=32), alphabet, syms,
+                          lambda: RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), rng)
+    print("  range K=256 uniform n=4096:", len(bits), "bits")
+    f256 = t256_table().tolist()
+    fr = Frequencies(dict(zip(alphabet, f256)))
+    for prec, sb in ((32, 32), (24, 13), (40, 32)):
+        if sum(f256) > (1 << (prec - 16)):
+            continue
+        p = RangeCoderParams(DATA_BLOCK_SIZE_BITS=sb, PRECISION=prec)
+        syms = iid_indices(f256, 1500, seed=4)
+        add_coder_case(col, "range", dict(group="G6p", freq=f256, precision=prec, size_bits=sb), alphabet, syms,
+                       lambda: RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), rng)
+
+
+def markov1(K, n, seed=4):
+    """S4 source of SURVEY.md 8d: order-1 Markov chain with Dirichlet(0.3) rows, x_0 drawn from row 0."""
+    rng = np.random.default_rng(seed)
+    P = rng.dirichlet(0.3 * np.ones(K), size=K)
+    x = np.zeros(n, dtype=np.uint8)
+    prev = 0
+    cdf = np.cumsum(P, axis=1)
+    u = rng.random(n)
+    for t in range(n):
+        prev = min(int(np.searchsorted(cdf[prev], u[t], side="right")), K - 1)
+        x[t] = prev
+    return x
+
+
+def markov2_ref(n, seed=0):
+    """the reference's test source (arithmetic_coding.py:384-402), restated as index data"""
+    rng = np.random.default_rng(seed)
+    random_bits = rng.choice(2, size=n - 2)
+    x = np.zeros(n, dtype=np.uint8)
+    x[0] = rng.choice(3)
+    x[1] = rng.choice(3)
+    for i in range(2, n):
+        x[i] = (x[i - 1] + x[i - 2] + random_bits[i - 2]) % 3
+    return x
+
+
+def gen_aec(col, rng):
+    # G7: fixed + adaptive-iid models (arithmetic_coding.py:305-317, :346-358), incl. PRECISION=16
+    sweep = [([1, 1, 2], {}), ([12, 34, 1, 45], {}), ([34, 35, 546, 1, 13, 245], dict(DATA_BLOCK_SIZE_BITS=12)),
+             ([5, 5, 5, 5, 5, 5], dict(DATA_BLOCK_SIZE_BITS=12, PRECISION=16))]
+    for fl, kw in sweep:
+        alphabet = list("ABCDEF"[: len(fl)])
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        p = AECParams(**kw)
+        syms = iid_indices(fl, 1000, seed=0)
+        for model_name, init in (("fixed", fl), ("iid", fl), ("iid", [1] * len(fl))):
+            fr_init = Frequencies(dict(zip(alphabet, init)))
+            if model_name == "fixed":
+                mk = lambda: FixedFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ)
+            else:
+                mk = lambda: AdaptiveIIDFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ)
+            add_coder_case(col, "aec", dict(group="G7", model=model_name, freq=init, K=len(fl), k=0,
+                                            max_total=p.MAX_ALLOWED_TOTAL_FREQ, precision=p.PRECISION,
+                                            size_bits=p.DATA_BLOCK_SIZE_BITS), alphabet, syms,
+                           lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+    # PRECISION=16 with long input exercises the halving rule of the adaptive model
+    fl = [3, 1, 7, 2]
+    alphabet = list("ABCD")
+    p = AECParams(PRECISION=16)
+    syms = iid_indices(fl, 40000, seed=5)
+    fr_init = Frequencies(dict(zip(alphabet, [1] * 4)))
+    mk = lambda: AdaptiveIIDFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ)
+    add_coder_case(col, "aec", dict(group="G7halve", model="iid", freq=[1] * 4, K=4, k=0, max_total=p.MAX_ALLOWED_TOTAL_FREQ,
+                                    precision=16, size_bits=32), alphabet, syms,
+                   lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+    # short blocks incl. length 1 (length 0 never terminates in the reference decoder, quirk Q5)
+    for n in (1, 2, 3, 9):
+        fl = [2, 1, 5]
+        alphabet = list("ABC")
+        p = AECParams()
+        fr_init = Frequencies(dict(zip(alphabet, fl)))
+        mk = lambda: AdaptiveIIDFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ)
+        add_coder_case(col, "aec", dict(group="G7short", model="iid", freq=fl, K=3, k=0, max_total=p.MAX_ALLOWED_TOTAL_FREQ,
+                                        precision=32, size_bits=32), alphabet, iid_indices(fl, n, seed=n),
+                       lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+    # empty block: encoder only
+    p = AECParams()
+    fr_init = Frequencies({"A": 1, "B": 2})
+    add_coder_case(col, "aec", dict(group="G7empty", model="fixed", freq=[1, 2], K=2, k=0, max_total=p.MAX_ALLOWED_TOTAL_FREQ,
+                                    precision=32, size_bits=32), ["A", "B"], [],
+                   lambda: ArithmeticEncoder(p, FixedFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ)), None, rng, decode=False)
+
+    # G8: order-k on the reference's 2nd-order Markov source, k = 0..3; k = 0 equals adaptive iid
+    x = markov2_ref(10000)
+    p = AECParams()
+    alphabet = [0, 1, 2]
+    streams = {}
+    for k in (0, 1, 2, 3):
+        mk = lambda: AdaptiveOrderKFreqModel(alphabet, k, p.MAX_ALLOWED_TOTAL_FREQ)
+        streams[k] = add_coder_case(col, "aec", dict(group="G8", model="orderk", freq=[1, 1, 1], K=3, k=k,
+                                                     max_total=p.MAX_ALLOWED_TOTAL_FREQ, precision=32, size_bits=32),
+                                    alphabet, x, lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+    iid = AdaptiveIIDFreqModel(Frequencies({0: 1, 1: 1, 2: 1}), p.MAX_ALLOWED_TOTAL_FREQ)
+    assert streams[0] == ArithmeticEncoder(p, iid).encode_block(DataBlock(x.tolist()))
+    # G8b: order-1 on Markov-1 chunks (BASELINE.json configs[3]) for K = 4, 16, 256
+    for K, n in ((4, 4096), (16, 4096), (256, 2048)):
+        x = markov1(K, n)
+        alphabet = list(range(K))
+        mk = lambda: AdaptiveOrderKFreqModel(alphabet, 1, p.MAX_ALLOWED_TOTAL_FREQ)
+        add_coder_case(col, "aec", dict(group="G8b", model="orderk", freq=[1] * K, K=K, k=1, max_total=p.MAX_ALLOWED_TOTAL_FREQ,
+                                        precision=32, size_bits=32), alphabet, x,
+                       lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+
+
+def main(out_dir):
+    for name, fn in (("rans", gen_rans), ("tans", gen_tans), ("range", gen_range), ("aec", gen_aec)):
+        col = Collector()
+        fn(col, np.random.default_rng(12345))
+        col.save(f"{out_dir}/golden_{name}.npz")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "/root/repo/tests/golden")

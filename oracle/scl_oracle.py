@@ -1,0 +1,199 @@
+"""ctypes binding of the CPU oracle (oracle/scl_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the package ``stanford_compression_library_amd``.
+
+Every function works on ONE chunk (one fresh coder) and returns packed MSB-first bytes + bit
+counts, mirroring one ``encode_block`` / ``decode_block`` call of the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libscl_oracle.so")
+
+E_CAPACITY, E_PARAM, E_TRUNCATED, E_STATE, E_SYMBOL, E_TOTAL = -1, -2, -3, -4, -5, -6
+MODEL_FIXED, MODEL_IID, MODEL_ORDERK = 0, 1, 2
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"oracle {what} failed with code {code}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "scl_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        u32, u64, i64 = C.c_uint32, C.c_uint64, C.c_int64
+        L.orc_rans_encode.argtypes = [u8p, u64, u32p, u32, u64, u32, u32, u8p, u64]
+        L.orc_rans_decode.argtypes = [u8p, u64, u32p, u32, u64, u32, u32, u8p, u64, u64p]
+        L.orc_tans_encode.argtypes = [u8p, u64, u32p, u32, u64, u32, u8p, u64]
+        L.orc_tans_decode.argtypes = [u8p, u64, u32p, u32, u64, u32, u8p, u64, u64p]
+        L.orc_tans_tables.argtypes = [u32p, u32, u64, u64p, u32p, u64p, u32p, u64p]
+        L.orc_range_encode.argtypes = [u8p, u64, u32p, u32, u32, u32, u8p, u64]
+        L.orc_range_decode.argtypes = [u8p, u64, u32p, u32, u32, u32, u8p, u64, u64p]
+        L.orc_aec_encode.argtypes = [u8p, u64, C.c_int, u32, u32, u32p, u64, u32, u32, u8p, u64]
+        L.orc_aec_decode.argtypes = [u8p, u64, C.c_int, u32, u32, u32p, u64, u32, u32, u8p, u64, u64p]
+        L.orc_rans_encode_batch.argtypes = [u8p, u64, u64, u32p, u32, u64, u32, u32, u8p, u64, u64p]
+        L.orc_rans_decode_batch.argtypes = [u8p, u64, u64, u64p, u32p, u32, u64, u32, u32, u8p, u64, u64p]
+        for name in ("orc_rans_encode", "orc_rans_decode", "orc_tans_encode", "orc_tans_decode",
+                     "orc_tans_tables", "orc_range_encode", "orc_range_decode", "orc_aec_encode",
+                     "orc_aec_decode", "orc_rans_encode_batch", "orc_rans_decode_batch"):
+            getattr(L, name).restype = i64
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _freq(f):
+    return np.ascontiguousarray(f, dtype=np.uint32)
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise OracleError(int(rc), what)
+    return int(rc)
+
+
+def _enc_out(n, bits_per_sym=64, extra=64):
+    return np.zeros(int(n) * bits_per_sym // 8 + extra, dtype=np.uint8)
+
+
+# ---- rANS ------------------------------------------------------------------------------------
+def rans_encode(sym, freq, RF=1 << 16, b=1, size_bits=32):
+    sym, f = _u8(sym), _freq(freq)
+    out = _enc_out(sym.size)
+    nb = _check(lib().orc_rans_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, RF, b,
+                                      size_bits, _p(out, C.c_uint8), out.size), "rans_encode")
+    return out[: (nb + 7) // 8].copy(), nb
+
+
+def rans_decode(packed, nbits, freq, RF=1 << 16, b=1, size_bits=32, cap=1 << 22):
+    buf, f = _u8(packed), _freq(freq)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    used = _check(lib().orc_rans_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF, b,
+                                        size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "rans_decode")
+    return out[: n.value].copy(), used
+
+
+# ---- tANS ------------------------------------------------------------------------------------
+def tans_encode(sym, freq, RF=1 << 16, size_bits=32):
+    sym, f = _u8(sym), _freq(freq)
+    out = _enc_out(sym.size)
+    nb = _check(lib().orc_tans_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, RF,
+                                      size_bits, _p(out, C.c_uint8), out.size), "tans_encode")
+    return out[: (nb + 7) // 8].copy(), nb
+
+
+def tans_decode(packed, nbits, freq, RF=1 << 16, size_bits=32, cap=1 << 22):
+    buf, f = _u8(packed), _freq(freq)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    used = _check(lib().orc_tans_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF,
+                                        size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "tans_decode")
+    return out[: n.value].copy(), used
+
+
+def tans_tables(freq, RF=1):
+    f = _freq(freq)
+    ns = int(RF) * int(f.astype(np.int64).sum())
+    enc = np.zeros(ns, np.uint64)
+    dsym = np.zeros(ns, np.uint32)
+    dxs = np.zeros(ns, np.uint64)
+    nb = np.zeros(f.size, np.uint32)
+    th = np.zeros(f.size, np.uint64)
+    _check(lib().orc_tans_tables(_p(f, C.c_uint32), f.size, RF, _p(enc, C.c_uint64), _p(nb, C.c_uint32),
+                                 _p(th, C.c_uint64), _p(dsym, C.c_uint32), _p(dxs, C.c_uint64)), "tans_tables")
+    return dict(enc=enc, nbits=nb, thresh=th, dec_sym=dsym, dec_xs=dxs)
+
+
+# ---- range coder -----------------------------------------------------------------------------
+def range_encode(sym, freq, precision=32, size_bits=32):
+    sym, f = _u8(sym), _freq(freq)
+    out = _enc_out(sym.size)
+    nb = _check(lib().orc_range_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, precision,
+                                       size_bits, _p(out, C.c_uint8), out.size), "range_encode")
+    return out[: (nb + 7) // 8].copy(), nb
+
+
+def range_decode(packed, nbits, freq, precision=32, size_bits=32, cap=1 << 22):
+    buf, f = _u8(packed), _freq(freq)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    used = _check(lib().orc_range_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, precision,
+                                         size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "range_decode")
+    return out[: n.value].copy(), used
+
+
+# ---- arithmetic coder ------------------------------------------------------------------------
+def aec_encode(sym, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32, size_bits=32):
+    sym = _u8(sym)
+    f = _freq(f_init if f_init is not None else np.ones(K))
+    out = _enc_out(sym.size, bits_per_sym=96, extra=256)
+    nb = _check(lib().orc_aec_encode(_p(sym, C.c_uint8), sym.size, model_kind, K, k, _p(f, C.c_uint32),
+                                     max_total, precision, size_bits, _p(out, C.c_uint8), out.size), "aec_encode")
+    return out[: (nb + 7) // 8].copy(), nb
+
+
+def aec_decode(packed, nbits, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32,
+               size_bits=32, cap=1 << 22):
+    buf = _u8(packed)
+    f = _freq(f_init if f_init is not None else np.ones(K))
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    used = _check(lib().orc_aec_decode(_p(buf, C.c_uint8), nbits, model_kind, K, k, _p(f, C.c_uint32),
+                                       max_total, precision, size_bits, _p(out, C.c_uint8), cap,
+                                       C.byref(n)), "aec_decode")
+    return out[: n.value].copy(), used
+
+
+# ---- batch helpers (timed CPU baseline) --------------------------------------------------------
+def rans_encode_batch(sym2d, freq, RF=1 << 16, b=1, size_bits=32, out_stride=None):
+    sym2d, f = _u8(sym2d), _freq(freq)
+    n_chunks, chunk_len = sym2d.shape
+    out_stride = out_stride or (chunk_len * 2 + 64)
+    out = np.zeros((n_chunks, out_stride), np.uint8)
+    nbits = np.zeros(n_chunks, np.uint64)
+    _check(lib().orc_rans_encode_batch(_p(sym2d, C.c_uint8), n_chunks, chunk_len, _p(f, C.c_uint32), f.size,
+                                       RF, b, size_bits, _p(out, C.c_uint8), out_stride,
+                                       _p(nbits, C.c_uint64)), "rans_encode_batch")
+    return out, nbits
+
+
+def rans_decode_batch(streams2d, nbits, freq, chunk_len, RF=1 << 16, b=1, size_bits=32):
+    streams2d, f = _u8(streams2d), _freq(freq)
+    nbits = np.ascontiguousarray(nbits, np.uint64)
+    n_chunks, stride = streams2d.shape
+    out = np.zeros((n_chunks, chunk_len), np.uint8)
+    consumed = np.zeros(n_chunks, np.uint64)
+    _check(lib().orc_rans_decode_batch(_p(streams2d, C.c_uint8), n_chunks, stride, _p(nbits, C.c_uint64),
+                                       _p(f, C.c_uint32), f.size, RF, b, size_bits, _p(out, C.c_uint8),
+                                       chunk_len, _p(consumed, C.c_uint64)), "rans_decode_batch")
+    return out, consumed

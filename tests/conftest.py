@@ -1,0 +1,59 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+class GoldenCase:
+    """One reference-generated vector (see oracle/gen_goldens.py)."""
+
+    def __init__(self, meta, arrays):
+        self.meta = meta
+        self._arrays = arrays
+
+    def __getattr__(self, k):
+        try:
+            return self.meta[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def arr(self, name):
+        return self._arrays[f"c{self.meta['id']}_{name}"]
+
+    @property
+    def bits_with_garbage(self):
+        """[(packed bytes, total bits, expected consumed)] for each stored garbage length."""
+        out = []
+        base = np.unpackbits(self.arr("out"))[: self.nbits]
+        for g, used in zip(self.meta.get("garbage_lens", []), self.meta.get("consumed", [])):
+            bits = np.concatenate([base, self.arr(f"garbage{g}").astype(np.uint8)])
+            out.append((np.packbits(bits), int(bits.size), used))
+        return out
+
+    def __repr__(self):
+        m = self.meta
+        return f"{m['kind']}[{m['id']}:{m.get('group')},n={m.get('n')}]"
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"golden_{name}.npz"))
+    manifest = json.loads(str(z["manifest"]))
+    arrays = {k: z[k] for k in z.files if k != "manifest"}
+    return [GoldenCase(m, arrays) for m in manifest]
+
+
+def golden_ids(cases):
+    return [repr(c) for c in cases]

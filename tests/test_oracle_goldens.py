@@ -1,0 +1,83 @@
+"""Pins the CPU oracle (oracle/scl_oracle.c) bit-for-bit against vectors generated from the
+imported reference (oracle/gen_goldens.py): encoder output bits, decoder symbols and
+``num_bits_consumed`` with 0 / 3 / 61 trailing garbage bits.  CPU only."""
+import numpy as np
+import pytest
+
+import scl_oracle as orc
+from conftest import golden_ids, load_golden
+
+RANS = [c for c in load_golden("rans")]
+TANS = [c for c in load_golden("tans") if c.kind == "tans"]
+TANS_TABLES = [c for c in load_golden("tans") if c.kind == "tans_tables"]
+RANGE = load_golden("range")
+AEC = load_golden("aec")
+MODEL = {"fixed": orc.MODEL_FIXED, "iid": orc.MODEL_IID, "orderk": orc.MODEL_ORDERK}
+
+
+def _same_stream(got_bytes, got_nbits, case):
+    assert got_nbits == case.nbits
+    assert np.array_equal(got_bytes, case.arr("out"))
+
+
+@pytest.mark.parametrize("case", RANS, ids=golden_ids(RANS))
+def test_rans(case):
+    out, nb = orc.rans_encode(case.arr("sym"), case.freq, RF=case.RF, b=case.b, size_bits=case.size_bits)
+    _same_stream(out, nb, case)
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = orc.rans_decode(packed, total, case.freq, RF=case.RF, b=case.b, size_bits=case.size_bits)
+        assert got_used == used == case.nbits
+        assert np.array_equal(sym, case.arr("sym"))
+
+
+@pytest.mark.parametrize("case", TANS, ids=golden_ids(TANS))
+def test_tans(case):
+    out, nb = orc.tans_encode(case.arr("sym"), case.freq, RF=case.RF, size_bits=case.size_bits)
+    _same_stream(out, nb, case)
+    # tANS stream == rANS stream for equal parameters
+    out_r, nb_r = orc.rans_encode(case.arr("sym"), case.freq, RF=case.RF, b=1, size_bits=case.size_bits)
+    assert nb_r == nb and np.array_equal(out_r, out)
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = orc.tans_decode(packed, total, case.freq, RF=case.RF, size_bits=case.size_bits)
+        assert got_used == used
+        assert np.array_equal(sym, case.arr("sym"))
+
+
+@pytest.mark.parametrize("case", TANS_TABLES, ids=golden_ids(TANS_TABLES))
+def test_tans_tables(case):
+    """the five lookup tables of the reference's KAT model (tANS.py:285-337)"""
+    t = orc.tans_tables(case.freq, RF=case.RF)
+    f = np.asarray(case.freq, dtype=np.int64)
+    c = np.concatenate([[0], np.cumsum(f)[:-1]])
+    L = int(case.RF * f.sum())
+    for s, xs, v in case.arr("enc_tab"):
+        assert t["enc"][case.RF * c[s] + xs - case.RF * f[s]] == v
+    for x, s, xs in case.arr("dec_tab"):
+        assert t["dec_sym"][x - L] == s and t["dec_xs"][x - L] == xs
+    assert np.array_equal(t["nbits"], case.arr("nbits_tab"))
+    assert np.array_equal(t["thresh"].astype(np.int64), case.arr("thresh_tab"))
+    nsb = int(2 * L - 1).bit_length()
+    for xs, nb in case.arr("expand_tab"):
+        assert nsb - int(xs).bit_length() == nb
+
+
+@pytest.mark.parametrize("case", RANGE, ids=golden_ids(RANGE))
+def test_range(case):
+    out, nb = orc.range_encode(case.arr("sym"), case.freq, precision=case.precision, size_bits=case.size_bits)
+    _same_stream(out, nb, case)
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = orc.range_decode(packed, total, case.freq, precision=case.precision, size_bits=case.size_bits)
+        assert got_used == used
+        assert np.array_equal(sym, case.arr("sym"))
+
+
+@pytest.mark.parametrize("case", AEC, ids=golden_ids(AEC))
+def test_aec(case):
+    kw = dict(model_kind=MODEL[case.model], K=case.K, k=case.k, f_init=case.freq, max_total=case.max_total,
+              precision=case.precision, size_bits=case.size_bits)
+    out, nb = orc.aec_encode(case.arr("sym"), **kw)
+    _same_stream(out, nb, case)
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = orc.aec_decode(packed, total, **kw)
+        assert got_used == used
+        assert np.array_equal(sym, case.arr("sym"))
