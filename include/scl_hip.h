@@ -1,0 +1,229 @@
+/*
+ * scl_hip.h -- C ABI of the MI355X (gfx950) batched entropy-coding core.
+ *
+ * This is the drop-in boundary for ONE path of the Stanford Compression Library: the per-symbol
+ * inner loops of its rANS / tANS / range / arithmetic coders.  Every "batch" entry point runs N
+ * independent chunks, one wavefront lane per chunk, and each chunk's output is bit-identical to
+ * one call of the reference method it replaces with a fresh coder object:
+ *
+ *   scl_rans_encode_batch   <->  rANSEncoder.encode_block        scl/compressors/rANS.py:186-210
+ *   scl_rans_decode_batch   <->  rANSDecoder.decode_block        scl/compressors/rANS.py:270-297
+ *   scl_tans_encode_batch   <->  tANSEncoder.encode_block        scl/compressors/tANS.py:159-193
+ *   scl_tans_decode_batch   <->  tANSDecoder.decode_block        scl/compressors/tANS.py:252-279
+ *   scl_range_encode_batch  <->  RangeEncoder.encode_block       scl/compressors/range_coder.py:188-207
+ *   scl_range_decode_batch  <->  RangeDecoder.decode_block       scl/compressors/range_coder.py:269-317
+ *   scl_aec_encode_batch    <->  ArithmeticEncoder.encode_block  scl/compressors/arithmetic_coding.py:80-161
+ *   scl_aec_decode_batch    <->  ArithmeticDecoder.decode_block  scl/compressors/arithmetic_coding.py:203-287
+ *   (model handles)         <->  rANSParams / tANSParams / RangeCoderParams+Frequencies /
+ *                                AECParams+FreqModelBase subclasses (probability_models.py:15-160)
+ *   scl_streams_compact     <->  the BitArray each encode_block returns (left-aligned bits) and,
+ *                                with SCL_COMPACT_FRAMED, EncodedBlockWriter.write_block
+ *                                (scl/core/encoded_stream.py:150-175)
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, opaque handles; no C++ or torch types.
+ *   - every function returns an int status: SCL_OK or a negative SCL_E_* code;
+ *     scl_last_error() gives a thread-local message for the last failure.
+ *   - pointers named d_* are DEVICE pointers (HBM) owned by the caller; h_* are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ *     on that stream; nothing synchronises unless stated.
+ *   - symbols are uint8 alphabet indices (position in Frequencies.freq_dict, prob_dist.py:193-205);
+ *     alphabets are limited to 256 entries.
+ *   - a bit stream is MSB-first packed bytes (bitarray "big" endianness, bitarray_utils.py:25).
+ *     A stream is described by (bit_offset, nbits): bit_offset is the absolute position of its
+ *     first bit counted from the buffer's base pointer.  Encoders WRITE these descriptors;
+ *     decoders READ them, so encoder output feeds the decoder without any repacking:
+ *       * rANS / tANS streams are produced back to front (the reference prepends every field,
+ *         rANS.py:196) and therefore end exactly at the end of their slot:
+ *           bit_offset[c] = 8*(c+1)*out_stride - nbits[c]
+ *         The slot bits in front of the stream are zero (this is the front padding of
+ *         scl/core/encoded_stream.py:23-46).
+ *       * range / arithmetic streams are produced front to back: bit_offset[c] = 8*c*out_stride.
+ *     scl_streams_compact turns either into dense, byte-aligned, left-aligned streams.
+ *   - per-chunk status words (d_status): 0 = ok, else a bit mask of SCL_ST_*.
+ *   - all buffers holding streams must be 16-byte aligned, strides multiples of 16 bytes, and the
+ *     input buffer of a decoder must stay readable for 16 bytes past the last stream byte.
+ */
+#ifndef SCL_HIP_H
+#define SCL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define SCL_OK 0
+#define SCL_E_PARAM (-2)    /* parameter set rejected (also what the reference asserts on)      */
+#define SCL_E_ALLOC (-7)    /* device / host allocation failed                                  */
+#define SCL_E_HIP (-8)      /* a HIP runtime call failed (see scl_last_error)                    */
+#define SCL_E_NODEVICE (-9) /* no gfx950 device visible                                          */
+#define SCL_E_CHUNK (-10)   /* host convenience call: the chunk's status word was non-zero       */
+
+/* per-chunk status bits */
+#define SCL_ST_CAPACITY 0x1u  /* output slot too small / block larger than out_cap              */
+#define SCL_ST_SYMBOL 0x2u    /* symbol index >= K              (KeyError, prob_dist.py:208)     */
+#define SCL_ST_TRUNCATED 0x4u /* decoder needed bits past in_nbits                               */
+#define SCL_ST_STATE 0x8u     /* final state != INITIAL_STATE   (assert, rANS.py:295)            */
+#define SCL_ST_TOTAL 0x10u    /* total_freq >= MAX_ALLOWED_TOTAL_FREQ (assert, arithmetic_coding.py:110) */
+#define SCL_ST_SIZE 0x20u     /* block size does not fit DATA_BLOCK_SIZE_BITS                    */
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *scl_last_error(void);
+int scl_device_count(int *count);
+int scl_abi_version(void);
+
+/* ---- rANS ---------------------------------------------------------------------------------- */
+typedef struct scl_rans_model scl_rans_model;
+
+typedef struct scl_rans_info {
+    uint64_t M, L, H;        /* rANSParams.M / .L / .H              (rANS.py:100-104)            */
+    uint32_t K;
+    uint32_t num_state_bits; /* rANSParams.NUM_STATE_BITS           (rANS.py:119)                */
+    uint32_t size_bits;      /* DATA_BLOCK_SIZE_BITS                                             */
+    uint32_t num_bits_out;   /* NUM_BITS_OUT                                                     */
+    uint32_t max_bits_per_symbol; /* worst-case field width, for slot sizing                     */
+    uint32_t fast_path;      /* 1 if the u32 / power-of-two-M / b=1 kernels serve this model      */
+} scl_rans_info;
+
+/* rANSParams(freqs, DATA_BLOCK_SIZE_BITS, NUM_BITS_OUT, RANGE_FACTOR) -> device-resident tables.
+   Rejects: K == 0 or > 256, any freq == 0, H >= 2^63 (quirks Q7/Q8), size_bits or num_bits_out
+   outside 1..32. */
+int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor,
+                          uint32_t num_bits_out, uint32_t size_bits, scl_rans_model **out);
+void scl_rans_model_destroy(scl_rans_model *m);
+int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info);
+/* bytes a slot must have so that any block of n symbols fits (multiple of 16) */
+uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols);
+
+/* chunk c reads symbols d_sym[c*sym_stride .. +len_c) with len_c = d_lens ? d_lens[c] : chunk_len */
+int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                          const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                          uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                          uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+
+/* chunk c decodes the stream (d_bit_offset[c], d_in_nbits[c]) of d_in into
+   d_out_sym[c*out_stride .. ); at most out_cap symbols.  d_out_lens[c] = block size from the
+   header, d_consumed[c] = num_bits_consumed (trailing bits are tolerated and not counted). */
+int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                          const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                          uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                          uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                          uint32_t *d_status, void *stream);
+
+/* ---- tANS (cached rANS: M power of two, NUM_BITS_OUT == 1; tANS.py:31-53) ------------------- */
+typedef struct scl_tans_model scl_tans_model;
+
+int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor,
+                          uint32_t size_bits, scl_tans_model **out);
+void scl_tans_model_destroy(scl_tans_model *m);
+int scl_tans_model_info(const scl_tans_model *m, scl_rans_info *info);
+uint64_t scl_tans_slot_bytes(const scl_tans_model *m, uint64_t n_symbols);
+/* copy the device lookup tables back (for parity with tANS.py:285-337); any pointer may be NULL.
+   h_enc / h_dec_sym / h_dec_xs have RANGE_FACTOR*M entries, h_nbits / h_thresh have K. */
+int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, uint32_t *h_nbits,
+                          uint32_t *h_thresh, uint32_t *h_dec_sym, uint32_t *h_dec_xs);
+int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                          const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                          uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                          uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                          const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                          uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                          uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                          uint32_t *d_status, void *stream);
+
+/* ---- range coder (RangeCoderParams + Frequencies; range_coder.py:55-86) --------------------- */
+typedef struct scl_range_model scl_range_model;
+
+/* Rejects: precision not a multiple of 8 in 16..32, any freq == 0, total_freq > BOTTOM
+   (asserts at range_coder.py:64,84-85). */
+int scl_range_model_create(const uint32_t *h_freq, uint32_t K, uint32_t precision,
+                           uint32_t size_bits, scl_range_model **out);
+void scl_range_model_destroy(scl_range_model *m);
+uint64_t scl_range_slot_bytes(const scl_range_model *m, uint64_t n_symbols);
+int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                           const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                           uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                           uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                           const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                           uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                           uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                           uint32_t *d_status, void *stream);
+
+/* ---- arithmetic coder (AECParams + frequency model; arithmetic_coding.py:20-56) ------------- */
+typedef struct scl_aec_model scl_aec_model;
+
+#define SCL_MODEL_FIXED 0  /* FixedFreqModel          probability_models.py:57-67               */
+#define SCL_MODEL_IID 1    /* AdaptiveIIDFreqModel    probability_models.py:70-92               */
+#define SCL_MODEL_ORDERK 2 /* AdaptiveOrderKFreqModel probability_models.py:95-160              */
+
+/* Every chunk starts from a FRESH copy of the model (the reference keeps model state across
+   encode_block calls of one object, quirk Q4; one chunk == one new encoder object).
+   h_freq_init: initial frequencies [K] for FIXED / IID (ignored for ORDERK, which starts from
+   all-ones counts).  order_k: context length for ORDERK (0..3).  max_total: the model's
+   max_allowed_total_freq.  precision 8..32. */
+int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init, uint32_t K, uint32_t order_k,
+                         uint64_t max_total, uint32_t precision, uint32_t size_bits,
+                         scl_aec_model **out);
+void scl_aec_model_destroy(scl_aec_model *m);
+uint64_t scl_aec_slot_bytes(const scl_aec_model *m, uint64_t n_symbols);
+/* bytes of device scratch the adaptive models need for n_chunks concurrent coders (0 for FIXED) */
+uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chunks);
+int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                         const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                         uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                         uint32_t *d_out_nbits, uint32_t *d_status, void *d_scratch,
+                         uint64_t scratch_bytes, void *stream);
+int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                         const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                         uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                         uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                         uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes,
+                         void *stream);
+
+/* ---- stream compaction / framing ------------------------------------------------------------ */
+#define SCL_COMPACT_DENSE 0  /* stream c left-aligned at byte d_out_byte_offset[c], zero tail   */
+#define SCL_COMPACT_FRAMED 1 /* EncodedBlockWriter framing per stream:
+                                [u32 BE payload bytes][3-bit pad count][pad zeros][stream bits]
+                                (encoded_stream.py:23-46,94-103,150-175)                         */
+
+/* Gathers n_chunks streams (d_bit_offset, d_nbits) of d_in into one dense buffer.
+   d_out_byte_offset has n_chunks+1 entries (exclusive prefix sum of the per-stream byte sizes;
+   the last entry is the total).  d_scratch must hold scl_streams_compact_scratch_bytes(n_chunks).
+   Fails per call (not per chunk): if the total exceeds out_capacity nothing past it is written
+   and d_out_byte_offset[n_chunks] still reports the required size. */
+uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks);
+int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                        uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                        uint64_t *d_out_byte_offset, void *d_scratch, void *stream);
+
+/* ---- host convenience (one chunk, host buffers; allocates, copies, runs N=1, synchronises) --- */
+/* These back the drop-in encode_block / decode_block of the Python classes.  h_out receives the
+   left-aligned stream (what BitArray.tobytes() would give); *nbits its length. */
+int scl_rans_encode_host(const scl_rans_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                         uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_rans_decode_host(const scl_rans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                         uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_tans_encode_host(const scl_tans_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                         uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_tans_decode_host(const scl_tans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                         uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_range_encode_host(const scl_range_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                          uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_range_decode_host(const scl_range_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                          uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_aec_encode_host(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                        uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_aec_decode_host(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                        uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+/* peek the DATA_BLOCK_SIZE_BITS header of a host stream (so callers can size h_out_sym) */
+int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
+                               uint64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCL_HIP_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of ``libscl_hip.so`` (the C ABI declared in include/scl_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing, cannot be loaded or reports
+no device, the product path raises.  (The CPU oracle lives in oracle/ and is test infrastructure.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libscl_hip.so")
+
+OK = 0
+E_PARAM, E_ALLOC, E_HIP, E_NODEVICE, E_CHUNK = -2, -7, -8, -9, -10
+ST_CAPACITY, ST_SYMBOL, ST_TRUNCATED, ST_STATE, ST_TOTAL, ST_SIZE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+MODEL_FIXED, MODEL_IID, MODEL_ORDERK = 0, 1, 2
+COMPACT_DENSE, COMPACT_FRAMED = 0, 1
+
+
+class SclHipError(RuntimeError):
+    """A call into libscl_hip.so failed (carries the status code and the library's message)."""
+
+    def __init__(self, code: int, what: str, message: str):
+        super().__init__(f"{what}: status {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class RansInfo(C.Structure):
+    _fields_ = [("M", C.c_uint64), ("L", C.c_uint64), ("H", C.c_uint64), ("K", C.c_uint32),
+                ("num_state_bits", C.c_uint32), ("size_bits", C.c_uint32), ("num_bits_out", C.c_uint32),
+                ("max_bits_per_symbol", C.c_uint32), ("fast_path", C.c_uint32)]
+
+
+_u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_vp, _u32, _u64, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+
+# name -> (restype, argtypes); device pointers travel as void* (integers from tensor.data_ptr())
+_ENC_BATCH = [_vp, _vp, _u64, _vp, _u32, _u64, _vp, _u64, _vp, _vp, _vp, _vp]
+_DEC_BATCH = [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _u32, _vp, _vp, _vp, _vp]
+_ENC_HOST = [_vp, _u8p, _u64, _u8p, _u64, _u64p]
+_DEC_HOST = [_vp, _u8p, _u64, _u8p, _u64, _u64p, _u64p]
+_SIGNATURES = {
+    "scl_last_error": (C.c_char_p, []),
+    "scl_device_count": (_int, [C.POINTER(_int)]),
+    "scl_abi_version": (_int, []),
+    "scl_rans_model_create": (_int, [_u32p, _u32, _u64, _u32, _u32, C.POINTER(_vp)]),
+    "scl_rans_model_destroy": (None, [_vp]),
+    "scl_rans_model_info": (_int, [_vp, C.POINTER(RansInfo)]),
+    "scl_rans_slot_bytes": (_u64, [_vp, _u64]),
+    "scl_rans_encode_batch": (_int, _ENC_BATCH),
+    "scl_rans_decode_batch": (_int, _DEC_BATCH),
+    "scl_rans_encode_host": (_int, _ENC_HOST),
+    "scl_rans_decode_host": (_int, _DEC_HOST),
+    "scl_tans_model_create": (_int, [_u32p, _u32, _u64, _u32, C.POINTER(_vp)]),
+    "scl_tans_model_destroy": (None, [_vp]),
+    "scl_tans_model_info": (_int, [_vp, C.POINTER(RansInfo)]),
+    "scl_tans_slot_bytes": (_u64, [_vp, _u64]),
+    "scl_tans_model_tables": (_int, [_vp, _u32p, _u32p, _u32p, _u32p, _u32p]),
+    "scl_tans_encode_batch": (_int, _ENC_BATCH),
+    "scl_tans_decode_batch": (_int, _DEC_BATCH),
+    "scl_tans_encode_host": (_int, _ENC_HOST),
+    "scl_tans_decode_host": (_int, _DEC_HOST),
+    "scl_range_model_create": (_int, [_u32p, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "scl_range_model_destroy": (None, [_vp]),
+    "scl_range_slot_bytes": (_u64, [_vp, _u64]),
+    "scl_range_encode_batch": (_int, _ENC_BATCH),
+    "scl_range_decode_batch": (_int, _DEC_BATCH),
+    "scl_range_encode_host": (_int, _ENC_HOST),
+    "scl_range_decode_host": (_int, _DEC_HOST),
+    "scl_aec_model_create": (_int, [_int, _u32p, _u32, _u32, _u64, _u32, _u32, C.POINTER(_vp)]),
+    "scl_aec_model_destroy": (None, [_vp]),
+    "scl_aec_slot_bytes": (_u64, [_vp, _u64]),
+    "scl_aec_scratch_bytes": (_u64, [_vp, _u64]),
+    "scl_aec_encode_batch": (_int, _ENC_BATCH[:-1] + [_vp, _u64, _vp]),
+    "scl_aec_decode_batch": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _vp]),
+    "scl_aec_encode_host": (_int, _ENC_HOST),
+    "scl_aec_decode_host": (_int, _DEC_HOST),
+    "scl_streams_compact_scratch_bytes": (_u64, [_u64]),
+    "scl_streams_compact": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp]),
+    "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load(path: str = None) -> C.CDLL:
+    """Load libscl_hip.so and declare every entry point of include/scl_hip.h.  Raises
+    ``SclHipError`` when the library was not built -- there is no fallback."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise SclHipError(E_NODEVICE, "load", f"{p} not found: build it with __graft_entry__.build() "
+                              "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        lib = C.CDLL(p)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the binding disagree
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    msg = load().scl_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise SclHipError(rc, what, last_error())
+
+
+def device_count() -> int:
+    n = _int(0)
+    rc = load().scl_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def require_device() -> None:
+    if device_count() < 1:
+        raise SclHipError(E_NODEVICE, "require_device", "no HIP device visible; the entropy-coding "
+                          "path runs on MI355X only (no CPU fallback): " + last_error())
+
+
+def u8_ptr(a: np.ndarray):
+    return a.ctypes.data_as(_u8p)
+
+
+def u32_ptr(a: np.ndarray):
+    return a.ctypes.data_as(_u32p)

@@ -1,0 +1,288 @@
+// scl_core.hip -- library plumbing: errors, device query, stream compaction / framing,
+// and the single-chunk host drivers behind the drop-in encode_block / decode_block.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "scl_common.h"
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void scl_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *scl_last_error(void) { return g_err; }
+
+extern "C" int scl_abi_version(void) { return SCL_ABI_VERSION; }
+
+extern "C" int scl_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        scl_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        if (count) *count = 0;
+        return SCL_E_NODEVICE;
+    }
+    if (count) *count = n;
+    return n > 0 ? SCL_OK : SCL_E_NODEVICE;
+}
+
+// ---- stream compaction ----------------------------------------------------------------------------
+// Layout of one output record:
+//   DENSE : ceil(nbits/8) bytes, stream left-aligned, zero tail bits
+//   FRAMED: [u32 BE payload_bytes][payload], payload = 3-bit pad count, pad zeros, stream bits
+//           (Padder.add_byte_padding + HeaderHandler.add_header, encoded_stream.py:23-46,94-103)
+#define CP_THREADS 256
+#define CP_ITEMS 8
+#define CP_TILE (CP_THREADS * CP_ITEMS)
+
+__device__ __forceinline__ u64 cp_record_bytes(u32 nbits, int mode) {
+    if (mode == SCL_COMPACT_FRAMED) return 4ull + (((u64)nbits + 3 + 7) >> 3);
+    return ((u64)nbits + 7) >> 3;
+}
+
+// pass 1: per-tile exclusive scan of record sizes -> d_off (tile-local), d_tile_sum
+__global__ void __launch_bounds__(CP_THREADS) cp_scan_tiles(const u32 *__restrict__ nbits, u64 n, int mode,
+                                                           u64 *__restrict__ off, u64 *__restrict__ tile_sum) {
+    __shared__ u64 s_part[CP_THREADS];
+    const u64 base = (u64)blockIdx.x * CP_TILE + (u64)threadIdx.x * CP_ITEMS;
+    u64 v[CP_ITEMS], run = 0;
+    for (int i = 0; i < CP_ITEMS; ++i) {
+        u64 idx = base + i;
+        v[i] = run;
+        run += (idx < n) ? cp_record_bytes(nbits[idx], mode) : 0;
+    }
+    s_part[threadIdx.x] = run;
+    __syncthreads();
+    // Hillis-Steele over the 256 per-thread sums
+    for (u32 d = 1; d < CP_THREADS; d <<= 1) {
+        u64 t = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const u64 excl = s_part[threadIdx.x] - run;
+    for (int i = 0; i < CP_ITEMS; ++i) {
+        u64 idx = base + i;
+        if (idx < n) off[idx] = excl + v[i];
+    }
+    if (threadIdx.x == CP_THREADS - 1) tile_sum[blockIdx.x] = s_part[threadIdx.x];
+}
+
+// pass 2: one workgroup scans the tile sums in place (exclusive) and stores the grand total
+__global__ void __launch_bounds__(CP_THREADS) cp_scan_sums(u64 *__restrict__ tile_sum, u64 n_tiles,
+                                                          u64 *__restrict__ total_out) {
+    __shared__ u64 s_part[CP_THREADS];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 start = 0; start < n_tiles; start += CP_THREADS) {
+        u64 idx = start + threadIdx.x;
+        u64 mine = (idx < n_tiles) ? tile_sum[idx] : 0;
+        s_part[threadIdx.x] = mine;
+        __syncthreads();
+        for (u32 d = 1; d < CP_THREADS; d <<= 1) {
+            u64 t = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (idx < n_tiles) tile_sum[idx] = s_carry + s_part[threadIdx.x] - mine;
+        __syncthreads();
+        if (threadIdx.x == CP_THREADS - 1) s_carry += s_part[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+// pass 3: add tile bases; entry n = total
+__global__ void cp_add_base(u64 *__restrict__ off, u64 n, const u64 *__restrict__ tile_sum,
+                            const u64 *__restrict__ total) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) off[idx] += tile_sum[idx / CP_TILE];
+    if (idx == n) off[n] = *total;
+}
+
+// pass 4: one wavefront per stream copies (bit-shifts) it to its record.
+// The record payload is `lead` bits (FRAMED: 3-bit pad count + pad zeros; DENSE: none) followed by
+// the stream; payload bytes [q, q+w) are assembled from at most 32 source bits.
+__device__ __forceinline__ u32 cp_payload_bits(const BitReader &r, u64 q, u32 w_bytes, u32 lead, u32 pad) {
+    const u64 b0 = 8 * q;
+    const u32 wb = 8 * w_bytes;
+    if (b0 >= lead) return r.peek_at(r.pos + b0 - lead, wb);
+    u32 v = 0;
+    if (b0 + wb > lead) v = r.peek_at(r.pos, (u32)(b0 + wb - lead));
+    if (q == 0) v |= pad << (wb - 3);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const u64 *__restrict__ bit_off,
+                                              const u32 *__restrict__ nbits, u64 n, int mode, u8 *__restrict__ out,
+                                              u64 out_capacity, const u64 *__restrict__ rec_off) {
+    const u32 lane = threadIdx.x & (SCL_WAVE - 1);
+    const u64 c = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / SCL_WAVE;
+    if (c >= n) return;
+    const u64 o0 = rec_off[c], o1 = rec_off[c + 1];
+    if (o1 > out_capacity) return;  // caller sees the required size in rec_off[n]
+    const u32 nb = nbits[c];
+    BitReader r;
+    r.init(in, ~0ull >> 1, bit_off[c], nb);  // every stream byte lies inside the caller's buffer
+    u8 *dst = out + o0;
+    u64 rec_bytes = o1 - o0;
+    u32 lead = 0, pad = 0;
+    if (mode == SCL_COMPACT_FRAMED) {
+        const u32 payload = (u32)(rec_bytes - 4);
+        pad = payload * 8 - 3 - nb;
+        lead = 3 + pad;
+        if (lane == 0) {
+            dst[0] = (u8)(payload >> 24);
+            dst[1] = (u8)(payload >> 16);
+            dst[2] = (u8)(payload >> 8);
+            dst[3] = (u8)payload;
+        }
+        dst += 4;
+        rec_bytes -= 4;
+    }
+    // unaligned head up to a 4-byte boundary of the destination, then whole words, then the tail
+    u64 head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3;
+    if (head > rec_bytes) head = rec_bytes;
+    for (u64 q = lane; q < head; q += SCL_WAVE) dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
+    const u64 n_words = (rec_bytes - head) / 4;
+    for (u64 w = lane; w < n_words; w += SCL_WAVE) {
+        const u64 q = head + 4 * w;
+        *reinterpret_cast<u32 *>(dst + q) = scl_bswap32(cp_payload_bits(r, q, 4, lead, pad));
+    }
+    for (u64 q = head + 4 * n_words + lane; q < rec_bytes; q += SCL_WAVE)
+        dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
+}
+
+extern "C" uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks) {
+    u64 n_tiles = (n_chunks + CP_TILE - 1) / CP_TILE;
+    return scl_round_up((n_tiles + 2) * sizeof(u64), 256);
+}
+
+extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                                   uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                                   uint64_t *d_out_byte_offset, void *d_scratch, void *stream) {
+    SCL_REQUIRE(mode == SCL_COMPACT_DENSE || mode == SCL_COMPACT_FRAMED, "compact: unknown mode %d", mode);
+    SCL_REQUIRE(d_in && d_bit_offset && d_nbits && d_out && d_out_byte_offset && d_scratch,
+                "compact: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_chunks == 0) {
+        SCL_HIP_TRY(hipMemsetAsync(d_out_byte_offset, 0, sizeof(u64), st));
+        return SCL_OK;
+    }
+    const u64 n_tiles = (n_chunks + CP_TILE - 1) / CP_TILE;
+    u64 *tile_sum = (u64 *)d_scratch;
+    u64 *total = tile_sum + n_tiles;
+    hipLaunchKernelGGL(cp_scan_tiles, dim3((u32)n_tiles), dim3(CP_THREADS), 0, st, d_nbits, n_chunks, mode,
+                       d_out_byte_offset, tile_sum);
+    hipLaunchKernelGGL(cp_scan_sums, dim3(1), dim3(CP_THREADS), 0, st, tile_sum, n_tiles, total);
+    hipLaunchKernelGGL(cp_add_base, dim3((u32)((n_chunks + 1 + 255) / 256)), dim3(256), 0, st, d_out_byte_offset,
+                       n_chunks, tile_sum, total);
+    const u64 waves_per_block = 256 / SCL_WAVE;
+    hipLaunchKernelGGL(cp_copy, dim3((u32)((n_chunks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, st,
+                       d_in, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+// ---- host convenience drivers -----------------------------------------------------------------------
+extern "C" int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
+                                          uint64_t *n_out) {
+    SCL_REQUIRE(h_in && n_out && size_bits >= 1 && size_bits <= 32, "block_size: bad arguments");
+    SCL_REQUIRE(in_nbits >= size_bits, "block_size: stream shorter than its size header");
+    u64 v = 0;
+    for (u32 i = 0; i < size_bits; ++i) v = (v << 1) | ((h_in[i >> 3] >> (7 - (i & 7))) & 1u);
+    *n_out = v;
+    return SCL_OK;
+}
+
+static int status_to_error(u32 st, const char *what) {
+    if (st == 0) return SCL_OK;
+    scl_set_error("%s: chunk status 0x%x%s%s%s%s%s%s", what, st, (st & SCL_ST_CAPACITY) ? " CAPACITY" : "",
+                  (st & SCL_ST_SYMBOL) ? " SYMBOL" : "", (st & SCL_ST_TRUNCATED) ? " TRUNCATED" : "",
+                  (st & SCL_ST_STATE) ? " STATE" : "", (st & SCL_ST_TOTAL) ? " TOTAL" : "",
+                  (st & SCL_ST_SIZE) ? " SIZE" : "");
+    return SCL_E_CHUNK;
+}
+
+int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 *h_sym, u64 n, u8 *h_out,
+                        u64 out_cap_bytes, u64 *nbits) {
+    SCL_REQUIRE(model && h_out && nbits && (h_sym || n == 0), "encode_host: null argument");
+    SCL_REQUIRE(n < (1ull << 32), "encode_host: block too large");
+    const u64 slot = call.slot_bytes(model, n);
+    const u64 scratch_bytes = call.scratch_bytes ? call.scratch_bytes(model) : 0;
+    ScratchDev d_sym, d_slot, d_meta, d_dense, d_scr, d_cscr;
+    int rc;
+    if ((rc = d_sym.alloc(n + 16)) || (rc = d_slot.alloc(slot)) || (rc = d_meta.alloc(64)) ||
+        (rc = d_dense.alloc(slot + 16)) || (rc = d_scr.alloc(scratch_bytes)) ||
+        (rc = d_cscr.alloc(scl_streams_compact_scratch_bytes(1))))
+        return rc;
+    u64 *d_bit_off = (u64 *)d_meta.p;           // [0]
+    u64 *d_rec_off = (u64 *)d_meta.p + 1;       // [1..2]
+    u32 *d_nbits = (u32 *)((u64 *)d_meta.p + 4);  // byte 32
+    u32 *d_status = d_nbits + 1;
+    if (n) SCL_HIP_TRY(hipMemcpy(d_sym.p, h_sym, n, hipMemcpyHostToDevice));
+    SCL_HIP_TRY(hipMemset(d_meta.p, 0, 64));
+    rc = call.run(model, (const u8 *)d_sym.p, (u32)n, (u8 *)d_slot.p, slot, d_bit_off, d_nbits, d_status, d_scr.p,
+                  scratch_bytes);
+    if (rc) return rc;
+    rc = scl_streams_compact((const u8 *)d_slot.p, d_bit_off, d_nbits, 1, SCL_COMPACT_DENSE, (u8 *)d_dense.p, slot + 16,
+                             d_rec_off, d_cscr.p, nullptr);
+    if (rc) return rc;
+    SCL_HIP_TRY(hipDeviceSynchronize());
+    u32 meta[2];
+    SCL_HIP_TRY(hipMemcpy(meta, d_nbits, 8, hipMemcpyDeviceToHost));
+    if ((rc = status_to_error(meta[1], "encode_host"))) return rc;
+    const u64 bytes = ((u64)meta[0] + 7) / 8;
+    if (bytes > out_cap_bytes) {
+        scl_set_error("encode_host: output needs %llu bytes, capacity %llu", (unsigned long long)bytes,
+                      (unsigned long long)out_cap_bytes);
+        return SCL_E_PARAM;
+    }
+    SCL_HIP_TRY(hipMemcpy(h_out, d_dense.p, bytes, hipMemcpyDeviceToHost));
+    *nbits = meta[0];
+    return SCL_OK;
+}
+
+int scl_host_decode_one(const HostDecodeCall &call, const void *model, const u8 *h_in, u64 in_nbits, u8 *h_out_sym,
+                        u64 out_cap, u64 *n_out, u64 *consumed) {
+    SCL_REQUIRE(model && h_in && n_out && consumed && (h_out_sym || out_cap == 0), "decode_host: null argument");
+    SCL_REQUIRE(in_nbits < (1ull << 32) && out_cap < (1ull << 32), "decode_host: stream too large");
+    const u64 in_bytes = (in_nbits + 7) / 8;
+    const u64 scratch_bytes = call.scratch_bytes ? call.scratch_bytes(model) : 0;
+    ScratchDev d_in, d_out, d_meta, d_scr;
+    int rc;
+    if ((rc = d_in.alloc(in_bytes + 32)) || (rc = d_out.alloc(out_cap + 16)) || (rc = d_meta.alloc(64)) ||
+        (rc = d_scr.alloc(scratch_bytes)))
+        return rc;
+    SCL_HIP_TRY(hipMemset(d_in.p, 0, in_bytes + 32));
+    SCL_HIP_TRY(hipMemcpy(d_in.p, h_in, in_bytes, hipMemcpyHostToDevice));
+    u64 h_bit_off = 0;
+    u32 h_nb = (u32)in_nbits;
+    u64 *d_bit_off = (u64 *)d_meta.p;
+    u32 *d_nb = (u32 *)((u64 *)d_meta.p + 1);
+    u32 *d_len = d_nb + 1, *d_used = d_nb + 2, *d_status = d_nb + 3;
+    SCL_HIP_TRY(hipMemset(d_meta.p, 0, 64));
+    SCL_HIP_TRY(hipMemcpy(d_bit_off, &h_bit_off, 8, hipMemcpyHostToDevice));
+    SCL_HIP_TRY(hipMemcpy(d_nb, &h_nb, 4, hipMemcpyHostToDevice));
+    rc = call.run(model, (const u8 *)d_in.p, in_bytes + 32, d_bit_off, d_nb, (u8 *)d_out.p, (u32)out_cap, d_len, d_used,
+                  d_status, d_scr.p, scratch_bytes);
+    if (rc) return rc;
+    SCL_HIP_TRY(hipDeviceSynchronize());
+    u32 meta[3];
+    SCL_HIP_TRY(hipMemcpy(meta, d_len, 12, hipMemcpyDeviceToHost));
+    *n_out = meta[0];
+    *consumed = meta[1];
+    if ((rc = status_to_error(meta[2], "decode_host"))) return rc;
+    if (meta[0]) SCL_HIP_TRY(hipMemcpy(h_out_sym, d_out.p, meta[0], hipMemcpyDeviceToHost));
+    return SCL_OK;
+}

@@ -1,0 +1,336 @@
+// scl_rans.hip -- batched rANS encode / decode for gfx950, one wavefront lane per chunk.
+//
+// Replaces the per-symbol loops of reference scl/compressors/rANS.py:
+//   rANSEncoder.encode_block :186-210  (shrink_state :149-161, rans_base_encode_step :138-147)
+//   rANSDecoder.decode_block :270-297  (rans_base_decode_step :234-249, expand_state :251-260)
+// Stream layout per chunk (bit-exact with the reference):
+//   [n : DATA_BLOCK_SIZE_BITS][x_final : NUM_STATE_BITS][field(s_{n-1})] ... [field(s_0)]
+// where field(s_i) = the low k*NUM_BITS_OUT bits of the pre-shrink state, MSB first.
+//
+// Two kernel families:
+//   * generic  : any M, NUM_BITS_OUT, RANGE_FACTOR with H < 2^63 (u32 or u64 state, real division,
+//                the reference's while-loops kept as loops).  Used for parameter sets outside the
+//                fast path; correctness first.
+//   * fast     : H < 2^32, M = 2^m <= 2^16, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r (the reference
+//                defaults with a power-of-two table, BASELINE.json configs[1]): closed-form shift
+//                count, exact reciprocal division, LDS-resident tables, slot -> symbol LUT decode.
+#include <string.h>
+
+#include "scl_common.h"
+
+struct RansDev {
+    u32 K;
+    u32 b;
+    u32 size_bits;
+    u32 nsb;
+    u64 M, RF, L;
+    u32 m_log2;  // log2(M) if M is a power of two, else 0xFFFFFFFF
+    const u32 *d_freq;
+    const u32 *d_cum;
+};
+
+struct scl_rans_model {
+    RansDev dev;
+    u64 H;
+    u32 max_bits_per_symbol;
+    u32 state32;  // H < 2^32
+    u32 fast;
+    u32 *d_freq;
+    u32 *d_cum;
+    // fast-path tables
+    uint4 *d_enc_tab;  // [K]  {f | k0<<16.., thresh, rcp, cum/cmpl}
+    u32 *d_dec_tab;    // [M]  slot -> packed {sym, f-1, slot-cum}
+};
+
+// =====================================================================================================
+// generic kernels
+// =====================================================================================================
+template <typename ST>
+__global__ void __launch_bounds__(256) rans_encode_generic(RansDev P, const u8 *__restrict__ sym, u64 sym_stride,
+                                                          const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
+                                                          u8 *__restrict__ out, u64 out_stride,
+                                                          u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
+                                                          u32 *__restrict__ status) {
+    __shared__ u32 s_f[256];
+    __shared__ u32 s_c[256];
+    scl_load_table(s_f, P.d_freq, P.K);
+    scl_load_table(s_c, P.d_cum, P.K);
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 n = lens ? lens[c] : chunk_len;
+    const u8 *src = sym + c * sym_stride;
+    BackBitWriter w;
+    w.init(out + c * out_stride, out_stride);
+    u32 st = 0;
+    ST x = (ST)P.L;  // INITIAL_STATE, rANS.py:116
+    const u32 b = P.b;
+    for (u32 i = 0; i < n; ++i) {
+        u32 s = src[i];
+        if (s >= P.K) {
+            st |= SCL_ST_SYMBOL;
+            s = 0;
+        }
+        const ST f = (ST)s_f[s];
+        // max_shrunk_state = RF*f*2^b - 1 <= H (rANS.py:112); shrink_state :149-161 emits the low
+        // b bits per step, each group in front of the previous one -> low k*b bits, MSB first
+        const ST max_shrunk = (ST)(((ST)P.RF * f) << b) - 1;
+        u32 kb = 0;
+        ST xs = x;
+        while (xs > max_shrunk) {
+            xs >>= b;
+            kb += b;
+        }
+        if (kb) {
+            const u64 field = (kb >= 64) ? (u64)x : ((u64)x & ((1ull << kb) - 1));
+            w.put64(field, kb);
+        }
+        // rans_base_encode_step :138-147
+        x = (xs / f) * (ST)P.M + (ST)s_c[s] + (xs % f);
+    }
+    w.put64((u64)x, P.nsb);
+    if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
+    w.put(n, P.size_bits);
+    const u64 total = w.finish();
+    if (w.overflow) st |= SCL_ST_CAPACITY;
+    out_bit_off[c] = (c + 1) * out_stride * 8 - total;
+    out_nbits[c] = (u32)total;
+    if (status) status[c] = st;
+}
+
+template <typename ST>
+__global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *__restrict__ in, u64 in_size_bytes,
+                                                          const u64 *__restrict__ bit_off,
+                                                          const u32 *__restrict__ in_nbits, u64 n_chunks,
+                                                          u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
+                                                          u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
+                                                          u32 *__restrict__ status) {
+    __shared__ u32 s_f[256];
+    __shared__ u32 s_c[256];
+    scl_load_table(s_f, P.d_freq, P.K);
+    scl_load_table(s_c, P.d_cum, P.K);
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    BitReader r;
+    r.init(in, in_size_bytes, bit_off[c], in_nbits[c]);
+    const u64 start = r.pos;
+    u32 st = 0;
+    u32 n = r.get(P.size_bits);
+    ST x = (ST)r.get64(P.nsb);
+    if (r.truncated) {
+        st |= SCL_ST_TRUNCATED;
+        n = 0;
+    }
+    out_lens[c] = n;
+    if (n > out_cap) {
+        st |= SCL_ST_CAPACITY;
+        n = 0;
+    }
+    u8 *dst = out_sym + c * out_stride;
+    const u32 b = P.b;
+    const ST M = (ST)P.M, L = (ST)P.L;
+    for (u32 i = n; i-- > 0;) {
+        // rans_base_decode_step :234-249
+        ST block_id, slot;
+        if (P.m_log2 != 0xFFFFFFFFu) {
+            block_id = x >> P.m_log2;
+            slot = x & (M - 1);
+        } else {
+            block_id = x / M;
+            slot = x - block_id * M;
+        }
+        // largest s with cum[s] <= slot (np.searchsorted side="right" - 1, :217-232)
+        u32 lo = 0, hi = P.K;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if ((ST)s_c[mid] <= slot)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        x = block_id * (ST)s_f[lo] + slot - (ST)s_c[lo];
+        // expand_state :251-260
+        while (x < L && !r.truncated) x = (ST)(x << b) + (ST)r.get(b);
+        dst[i] = (u8)lo;  // decoded last symbol first (:291)
+        if (r.truncated) break;
+    }
+    if (r.truncated) st |= SCL_ST_TRUNCATED;
+    else if (x != L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE, :295
+    consumed[c] = (u32)(r.pos - start);
+    if (status) status[c] = st;
+}
+
+// =====================================================================================================
+// host API
+// =====================================================================================================
+static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bits, scl_rans_model **out) {
+    SCL_REQUIRE(out, "rans_model_create: null output");
+    *out = nullptr;
+    SCL_REQUIRE(h_freq && K >= 1 && K <= 256, "rans_model_create: alphabet size %u outside 1..256", K);
+    SCL_REQUIRE(b >= 1 && b <= 32, "rans_model_create: NUM_BITS_OUT %u outside 1..32", b);
+    SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "rans_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32",
+                size_bits);
+    SCL_REQUIRE(RF >= 1, "rans_model_create: RANGE_FACTOR must be >= 1");
+    unsigned __int128 M = 0;
+    u32 cum[256];
+    u32 fmin = 0xFFFFFFFFu;
+    for (u32 i = 0; i < K; ++i) {
+        SCL_REQUIRE(h_freq[i] > 0, "rans_model_create: zero frequency for symbol %u (division by zero, rANS.py:143)", i);
+        SCL_REQUIRE(M < (1ull << 31), "rans_model_create: total frequency too large");
+        cum[i] = (u32)M;
+        M += h_freq[i];
+        if (h_freq[i] < fmin) fmin = h_freq[i];
+    }
+    SCL_REQUIRE(M < (1ull << 31), "rans_model_create: total frequency too large");
+    unsigned __int128 L = (unsigned __int128)RF * M;
+    unsigned __int128 H = (L << b) - 1;
+    SCL_REQUIRE((H >> 63) == 0, "rans_model_create: H >= 2^63 overflows the reference's int64 state (quirk Q7)");
+    scl_rans_model *m = new scl_rans_model();
+    ::memset((void *)m, 0, sizeof(*m));
+    m->dev.K = K;
+    m->dev.b = b;
+    m->dev.size_bits = size_bits;
+    m->dev.M = (u64)M;
+    m->dev.RF = RF;
+    m->dev.L = (u64)L;
+    m->H = (u64)H;
+    m->dev.nsb = scl_bit_width_u64(m->H);
+    m->dev.m_log2 = ((u64)M & ((u64)M - 1)) == 0 ? (scl_bit_width_u64((u64)M) - 1) : 0xFFFFFFFFu;
+    m->state32 = (m->H >> 32) == 0 && b < 32;
+    // worst-case field: state H shrunk to <= RF*fmin*2^b - 1 in steps of b bits
+    {
+        unsigned __int128 ms = (((unsigned __int128)RF * fmin) << b) - 1, x = H;
+        u32 kb = 0;
+        while (x > ms) {
+            x >>= b;
+            kb += b;
+        }
+        m->max_bits_per_symbol = kb;
+    }
+    hipError_t e = hipMalloc((void **)&m->d_freq, 256 * sizeof(u32));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
+    if (e == hipSuccess) e = hipMemcpy(m->d_freq, h_freq, K * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        scl_set_error("rans_model_create: device table upload failed: %s", hipGetErrorString(e));
+        scl_rans_model_destroy(m);
+        return SCL_E_HIP;
+    }
+    m->dev.d_freq = m->d_freq;
+    m->dev.d_cum = m->d_cum;
+    *out = m;
+    return SCL_OK;
+}
+
+extern "C" int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor,
+                                     uint32_t num_bits_out, uint32_t size_bits, scl_rans_model **out) {
+    return rans_model_build(h_freq, K, range_factor, num_bits_out, size_bits, out);
+}
+
+extern "C" void scl_rans_model_destroy(scl_rans_model *m) {
+    if (!m) return;
+    if (m->d_freq) (void)hipFree(m->d_freq);
+    if (m->d_cum) (void)hipFree(m->d_cum);
+    if (m->d_enc_tab) (void)hipFree(m->d_enc_tab);
+    if (m->d_dec_tab) (void)hipFree(m->d_dec_tab);
+    delete m;
+}
+
+extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info) {
+    SCL_REQUIRE(m && info, "rans_model_info: null argument");
+    info->M = m->dev.M;
+    info->L = m->dev.L;
+    info->H = m->H;
+    info->K = m->dev.K;
+    info->num_state_bits = m->dev.nsb;
+    info->size_bits = m->dev.size_bits;
+    info->num_bits_out = m->dev.b;
+    info->max_bits_per_symbol = m->max_bits_per_symbol;
+    info->fast_path = m->fast;
+    return SCL_OK;
+}
+
+extern "C" uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols) {
+    if (!m) return 0;
+    const u64 bits = (u64)m->dev.size_bits + m->dev.nsb + n_symbols * (u64)m->max_bits_per_symbol;
+    return scl_round_up((bits + 7) / 8 + 4, 16);
+}
+
+static int check_batch_args(const char *what, const void *m, const void *a, const void *b, const void *c,
+                            const void *d, u64 stride) {
+    SCL_REQUIRE(m && a && b && c && d, "%s: null pointer argument", what);
+    SCL_REQUIRE(stride % 16 == 0 && stride > 0, "%s: stream stride %llu is not a positive multiple of 16", what,
+                (unsigned long long)stride);
+    return SCL_OK;
+}
+
+extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                     const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks, uint8_t *d_out,
+                                     uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
+                                     uint32_t *d_status, void *stream) {
+    int rc = check_batch_args("rans_encode_batch", m, d_sym, d_out, d_out_bit_offset, d_out_nbits, out_stride);
+    if (rc) return rc;
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "rans_encode_batch: d_out must be 16-byte aligned");
+    SCL_REQUIRE(out_stride * 8 < (1ull << 32), "rans_encode_batch: slot larger than 512 MiB");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    if (m->state32)
+        hipLaunchKernelGGL(rans_encode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
+    else
+        hipLaunchKernelGGL(rans_encode_generic<u64>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                     const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
+                                     uint8_t *d_out_sym, uint64_t out_stride, uint32_t out_cap, uint32_t *d_out_lens,
+                                     uint32_t *d_consumed, uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "rans_decode_batch: null pointer argument");
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "rans_decode_batch: d_in must be 4-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    if (m->state32)
+        hipLaunchKernelGGL(rans_decode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                           d_status);
+    else
+        hipLaunchKernelGGL(rans_decode_generic<u64>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                           d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+// ---- single-chunk host drivers ------------------------------------------------------------------------
+static int rans_run_enc(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                        u32 *d_nbits, u32 *d_status, void *, u64) {
+    return scl_rans_encode_batch((const scl_rans_model *)model, d_sym, n, nullptr, n, 1, d_out, out_stride, d_bit_off,
+                                 d_nbits, d_status, nullptr);
+}
+static u64 rans_slot(const void *model, u64 n) { return scl_rans_slot_bytes((const scl_rans_model *)model, n); }
+static int rans_run_dec(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
+                        u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *, u64) {
+    return scl_rans_decode_batch((const scl_rans_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1, d_out_sym,
+                                 scl_round_up((u64)out_cap + 1, 16), out_cap, d_out_len, d_consumed, d_status, nullptr);
+}
+
+extern "C" int scl_rans_encode_host(const scl_rans_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                                    uint64_t out_cap_bytes, uint64_t *nbits) {
+    HostEncodeCall call = {rans_run_enc, rans_slot, nullptr};
+    return scl_host_encode_one(call, m, h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_rans_decode_host(const scl_rans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                    uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
+    HostDecodeCall call = {rans_run_dec, nullptr};
+    return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}
