@@ -1,0 +1,242 @@
+"""Device model handles + the two call shapes of the C ABI (include/scl_hip.h):
+
+* ``encode_host`` / ``decode_host`` -- one chunk in host memory (what the drop-in ``encode_block`` /
+  ``decode_block`` classes use; the library allocates, copies, runs N = 1 and synchronises);
+* ``encode_batch`` / ``decode_batch`` -- N chunks already resident in HBM, given as torch tensors
+  (torch is only the allocator / stream provider here).
+
+Everything raises ``SclHipError`` when the HIP library or a device is missing: no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def _freq_array(freq_list) -> np.ndarray:
+    arr = np.ascontiguousarray(np.asarray([int(f) for f in freq_list], dtype=np.int64))
+    if arr.size and (arr.min() < 0 or arr.max() >= (1 << 32)):
+        raise AssertionError("frequencies must fit an unsigned 32-bit integer")
+    return arr.astype(np.uint32)
+
+
+@dataclass
+class EncodedBatch:
+    """Device-resident result of a batched encode: ``data`` holds one slot of ``stride`` bytes per chunk;
+    stream c is the ``nbits[c]`` bits starting at absolute bit ``bit_offset[c]`` of ``data``."""
+
+    data: "torch.Tensor"        # uint8 [n_chunks * stride + 16]
+    stride: int
+    bit_offset: "torch.Tensor"  # uint64 as int64 [n_chunks]
+    nbits: "torch.Tensor"       # uint32 as int32 [n_chunks]
+    status: "torch.Tensor"      # uint32 as int32 [n_chunks]
+    n_chunks: int
+
+
+class _DeviceModel:
+    """Common part of the four model kinds; subclasses set ``_prefix`` and create the handle."""
+
+    _prefix = ""
+    _needs_scratch = False
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._L = _lib.load()
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            getattr(self._L, f"scl_{self._prefix}_model_destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fn(self, name):
+        return getattr(self._L, f"scl_{self._prefix}_{name}")
+
+    def slot_bytes(self, n_symbols: int) -> int:
+        return int(self._fn("slot_bytes")(self._h, int(n_symbols)))
+
+    # -- one chunk, host memory -------------------------------------------------------------------
+    def encode_host(self, sym: np.ndarray):
+        """uint8 index array -> (packed MSB-first bytes, nbits), left-aligned like BitArray.tobytes()."""
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        cap = self.slot_bytes(sym.size) + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        nbits = C.c_uint64(0)
+        rc = self._fn("encode_host")(self._h, _lib.u8_ptr(sym), sym.size, _lib.u8_ptr(out), cap, C.byref(nbits))
+        _lib.check(rc, f"scl_{self._prefix}_encode_host")
+        return out[: (nbits.value + 7) // 8], int(nbits.value)
+
+    def decode_host(self, packed: np.ndarray, nbits: int, size_bits: int):
+        """(packed bytes, available bits) -> (uint8 index array, num_bits_consumed)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
+        _lib.check(rc, "scl_stream_block_size_host")
+        out = np.zeros(max(int(n.value), 1), dtype=np.uint8)
+        n_out, used = C.c_uint64(0), C.c_uint64(0)
+        rc = self._fn("decode_host")(self._h, _lib.u8_ptr(packed), int(nbits), _lib.u8_ptr(out), int(n.value),
+                                     C.byref(n_out), C.byref(used))
+        _lib.check(rc, f"scl_{self._prefix}_decode_host")
+        return out[: n_out.value], int(used.value)
+
+    # -- N chunks, device memory (torch tensors) ----------------------------------------------------
+    def _scratch(self, n_chunks, device):
+        import torch
+
+        if not self._needs_scratch:
+            return None, 0
+        nbytes = int(self._L.scl_aec_scratch_bytes(self._h, int(n_chunks)))
+        if nbytes == 0:
+            return None, 0
+        return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+    def encode_batch(self, sym, lens=None, out_stride: Optional[int] = None, stream=None) -> EncodedBatch:
+        """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks]."""
+        import torch
+
+        assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
+        n_chunks, chunk_len = sym.shape
+        stride = int(out_stride or self.slot_bytes(chunk_len))
+        dev = sym.device
+        data = torch.empty(n_chunks * stride + 16, dtype=torch.uint8, device=dev)
+        bit_off = torch.empty(n_chunks, dtype=torch.int64, device=dev)
+        nbits = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        status = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        args = [self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None,
+                chunk_len, n_chunks, data.data_ptr(), stride, bit_off.data_ptr(), nbits.data_ptr(),
+                status.data_ptr()]
+        if self._needs_scratch:
+            scratch, nbytes = self._scratch(n_chunks, dev)
+            args += [scratch.data_ptr() if scratch is not None else None, nbytes]
+            self._last_scratch = scratch  # keep alive until the stream is done
+        rc = self._fn("encode_batch")(*args, st)
+        _lib.check(rc, f"scl_{self._prefix}_encode_batch")
+        return EncodedBatch(data, stride, bit_off, nbits, status, n_chunks)
+
+    def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None):
+        """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device."""
+        import torch
+
+        assert data.is_cuda and data.dtype == torch.uint8
+        n_chunks = int(bit_offset.numel())
+        dev = data.device
+        out_stride = (int(chunk_cap) + 15) // 16 * 16
+        sym = torch.empty((n_chunks, out_stride), dtype=torch.uint8, device=dev)
+        lens = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        used = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        status = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        args = [self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
+                sym.data_ptr(), out_stride, int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr()]
+        if self._needs_scratch:
+            scratch, nbytes = self._scratch(n_chunks, dev)
+            args += [scratch.data_ptr() if scratch is not None else None, nbytes]
+            self._last_scratch = scratch
+        rc = self._fn("decode_batch")(*args, st)
+        _lib.check(rc, f"scl_{self._prefix}_decode_batch")
+        return sym[:, :chunk_cap], lens, used, status
+
+
+class RansModel(_DeviceModel):
+    _prefix = "rans"
+
+    def __init__(self, freq_list, range_factor: int, num_bits_out: int, size_bits: int):
+        super().__init__()
+        f = _freq_array(freq_list)
+        rc = self._L.scl_rans_model_create(_lib.u32_ptr(f), f.size, int(range_factor), int(num_bits_out),
+                                           int(size_bits), C.byref(self._h))
+        _lib.check(rc, "scl_rans_model_create")
+        self.size_bits = int(size_bits)
+
+    def info(self) -> _lib.RansInfo:
+        info = _lib.RansInfo()
+        _lib.check(self._L.scl_rans_model_info(self._h, C.byref(info)), "scl_rans_model_info")
+        return info
+
+
+class TansModel(_DeviceModel):
+    _prefix = "tans"
+
+    def __init__(self, freq_list, range_factor: int, size_bits: int):
+        super().__init__()
+        f = _freq_array(freq_list)
+        rc = self._L.scl_tans_model_create(_lib.u32_ptr(f), f.size, int(range_factor), int(size_bits),
+                                           C.byref(self._h))
+        _lib.check(rc, "scl_tans_model_create")
+        self.size_bits = int(size_bits)
+        self.K = int(f.size)
+
+    def info(self) -> _lib.RansInfo:
+        info = _lib.RansInfo()
+        _lib.check(self._L.scl_tans_model_info(self._h, C.byref(info)), "scl_tans_model_info")
+        return info
+
+    def tables(self):
+        """The device-built lookup tables as numpy arrays (enc, nbits, thresh, dec_sym, dec_xs)."""
+        L = int(self.info().L)
+        enc, dsym, dxs = (np.zeros(L, np.uint32) for _ in range(3))
+        nb, th = np.zeros(self.K, np.uint32), np.zeros(self.K, np.uint32)
+        rc = self._L.scl_tans_model_tables(self._h, _lib.u32_ptr(enc), _lib.u32_ptr(nb), _lib.u32_ptr(th),
+                                           _lib.u32_ptr(dsym), _lib.u32_ptr(dxs))
+        _lib.check(rc, "scl_tans_model_tables")
+        return dict(enc=enc, nbits=nb, thresh=th, dec_sym=dsym, dec_xs=dxs)
+
+
+class RangeModel(_DeviceModel):
+    _prefix = "range"
+
+    def __init__(self, freq_list, precision: int, size_bits: int):
+        super().__init__()
+        f = _freq_array(freq_list)
+        rc = self._L.scl_range_model_create(_lib.u32_ptr(f), f.size, int(precision), int(size_bits),
+                                            C.byref(self._h))
+        _lib.check(rc, "scl_range_model_create")
+        self.size_bits = int(size_bits)
+
+
+class AecModel(_DeviceModel):
+    _prefix = "aec"
+    _needs_scratch = True
+
+    def __init__(self, model_kind: int, freq_init, K: int, order_k: int, max_total: int, precision: int,
+                 size_bits: int):
+        super().__init__()
+        f = _freq_array(freq_init if freq_init is not None else [1] * K)
+        rc = self._L.scl_aec_model_create(int(model_kind), _lib.u32_ptr(f), int(K), int(order_k), int(max_total),
+                                          int(precision), int(size_bits), C.byref(self._h))
+        _lib.check(rc, "scl_aec_model_create")
+        self.size_bits = int(size_bits)
+
+
+def compact(enc: EncodedBatch, framed: bool = False, stream=None):
+    """Dense (or EncodedBlockWriter-framed) concatenation of a batch: -> (bytes tensor, int64 offsets[n+1])."""
+    import torch
+
+    L = _lib.load()
+    dev = enc.data.device
+    n = enc.n_chunks
+    # capacity: every record is at most ceil(nbits/8) (+5 framed) bytes
+    total_bits = int(enc.nbits.to(torch.int64).sum().item())
+    cap = total_bits // 8 + n * (6 if framed else 1) + 16
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(int(L.scl_streams_compact_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), n,
+                               _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), cap,
+                               offsets.data_ptr(), scratch.data_ptr(), st)
+    _lib.check(rc, "scl_streams_compact")
+    torch.cuda.current_stream(dev).synchronize()
+    return out, offsets

@@ -1,0 +1,30 @@
+"""Shared glue of the four drop-in coder pairs: symbol <-> alphabet-index mapping and BitArray packing."""
+from __future__ import annotations
+
+import numpy as np
+
+from ..core.data_block import DataBlock
+from ..utils.bitarray_utils import BitArray
+
+
+def symbols_to_indices(data_block: DataBlock, index_of: dict) -> np.ndarray:
+    """Map a block's symbols to uint8 alphabet indices; an unknown symbol raises ``KeyError`` exactly like
+    ``Frequencies.frequency`` in the reference (prob_dist.py:207-208)."""
+    data = data_block.data_list
+    if isinstance(data, np.ndarray):
+        data = data.tolist()
+    return np.fromiter((index_of[s] for s in data), dtype=np.uint8, count=len(data))
+
+
+def indices_to_block(idx: np.ndarray, alphabet: list) -> DataBlock:
+    return DataBlock([alphabet[i] for i in idx.tolist()])
+
+
+def bitarray_to_packed(bits: BitArray):
+    return bits.packed(), len(bits)
+
+
+def check_alphabet(alphabet):
+    if len(alphabet) > 256:
+        raise NotImplementedError(
+            f"alphabet of {len(alphabet)} symbols: the MI355X kernels carry symbols as uint8 indices (<= 256)")

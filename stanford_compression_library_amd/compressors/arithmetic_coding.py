@@ -1,0 +1,85 @@
+"""Finite-precision arithmetic coder with the reference's class API, executed by the gfx950 kernels.
+
+Drop-in for reference scl/compressors/arithmetic_coding.py: ``AECParams`` (:20-38), ``ArithmeticEncoder``
+(:41-161), ``ArithmeticDecoder`` (:164-287).  Kernels: ``csrc/scl_aec.hip``.
+
+Difference from the reference, stated once: an encoder / decoder object here starts every
+``encode_block`` / ``decode_block`` from a *fresh* copy of the model it was constructed with -- the unit
+the device batches is one chunk = one new coder.  The reference mutates ``freq_model`` across calls (it
+never overrides ``reset()``, quirk Q4), so a reference object used for several blocks is matched by one
+object per block here.  The first block of any object is bit-identical.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Tuple
+
+from ..backend.models import AecModel
+from ..core.data_block import DataBlock
+from ..core.data_encoder_decoder import DataDecoder, DataEncoder
+from ..utils.bitarray_utils import BitArray
+from ._common import check_alphabet, indices_to_block, symbols_to_indices
+from .probability_models import FreqModelBase
+
+__all__ = ["AECParams", "ArithmeticEncoder", "ArithmeticDecoder"]
+
+
+@dataclass
+class AECParams:
+    DATA_BLOCK_SIZE_BITS: int = 32
+    PRECISION: int = 32
+
+    def __post_init__(self):
+        self.FULL: int = 1 << self.PRECISION
+        self.HALF: int = 1 << (self.PRECISION - 1)
+        self.QTR: int = 1 << (self.PRECISION - 2)
+        self.MAX_ALLOWED_TOTAL_FREQ: int = self.QTR
+        self.MAX_BLOCK_SIZE: int = 1 << self.DATA_BLOCK_SIZE_BITS
+
+
+class _AecBase:
+    def __init__(self, params: AECParams, freq_model: FreqModelBase):
+        self.params = params
+        self.freq_model = freq_model
+        self._model = None
+
+    def _device_model(self) -> AecModel:
+        if self._model is None:
+            spec = self.freq_model.device_spec()
+            check_alphabet(spec["alphabet"])
+            if not 8 <= self.params.PRECISION <= 32:
+                raise NotImplementedError("PRECISION outside 8..32: the gfx950 kernels keep low/high in 33 bits")
+            self._model = AecModel(spec["kind"], spec["freq_init"], spec["K"], spec["k"], spec["max_total"],
+                                   self.params.PRECISION, self.params.DATA_BLOCK_SIZE_BITS)
+            self._alphabet = list(spec["alphabet"])
+            self._index_of = {a: i for i, a in enumerate(self._alphabet)}
+        return self._model
+
+
+class ArithmeticEncoder(_AecBase, DataEncoder):
+    def encode_block(self, data_block: DataBlock) -> BitArray:
+        """[size | renormalisation bits | termination bits] -- arithmetic_coding.py:80-161.
+        The reference's ``size < 1 << MAX_BLOCK_SIZE`` assert (a 2^32-bit integer, quirk Q3) is replaced by
+        the intended check against DATA_BLOCK_SIZE_BITS."""
+        from ..backend.lib import E_CHUNK, SclHipError
+
+        model = self._device_model()
+        idx = symbols_to_indices(data_block, self._index_of)
+        assert data_block.size < self.params.MAX_BLOCK_SIZE, \
+            "choose a larger DATA_BLOCK_SIZE_BITS, as data_block.size is too big"
+        try:
+            packed, nbits = model.encode_host(idx)
+        except SclHipError as e:
+            if e.code == E_CHUNK and "TOTAL" in e.message:
+                raise AssertionError("the frequency total is too large (>= MAX_ALLOWED_TOTAL_FREQ)") from e
+            raise
+        return BitArray.from_packed(packed, nbits)
+
+
+class ArithmeticDecoder(_AecBase, DataDecoder):
+    def decode_block(self, encoded_bitarray: BitArray) -> Tuple[DataBlock, int]:
+        """-> (DataBlock, num_bits_consumed); trailing bits are tolerated -- arithmetic_coding.py:203-287."""
+        model = self._device_model()
+        idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
+                                      self.params.DATA_BLOCK_SIZE_BITS)
+        return indices_to_block(idx, self._alphabet), used

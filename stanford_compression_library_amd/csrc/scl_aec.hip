@@ -1,0 +1,488 @@
+// scl_aec.hip -- batched finite-precision arithmetic coder with pluggable frequency models for
+// gfx950, one wavefront lane per chunk (one coder + one private model per lane).
+//
+// Replaces reference scl/compressors/arithmetic_coding.py
+//   AECParams :20-38, ArithmeticEncoder.shrink_range :58-78, encode_block :80-161,
+//   ArithmeticDecoder.decode_step_core :177-201, decode_block :203-287
+// and scl/compressors/probability_models.py
+//   FixedFreqModel :57-67, AdaptiveIIDFreqModel :70-92, AdaptiveOrderKFreqModel :95-160.
+// Stream layout per chunk: [n : DATA_BLOCK_SIZE_BITS][renormalisation bits ...][termination bits].
+//
+// Reference behaviours reproduced on purpose:
+//   * strict comparisons `high < HALF`, `low > HALF`, `low > QTR and high < 3*QTR`, final `low <= QTR`;
+//   * the model is updated after shrink_range and before renormalisation; the decoder stops before the
+//     last renormalisation and then works out how many of the last PRECISION bits were its own;
+//   * one chunk == one FRESH model (the reference keeps model state across encode_block calls of one
+//     object; batched chunks correspond to one new encoder object per chunk).
+// Deliberately not inherited (quirks Q3/Q5): the 2^(2^32)-bit assert; decoding an empty block never
+// terminates in the reference -- here it returns the header plus the two termination bits.
+//
+// The decoder's vector search  max{s : low + (c[s]*rng)//T <= state}  (:195-200) is evaluated through the
+// exact integer equivalence  c[s] <= ((state - low + 1)*T - 1) // rng  and a scan of the model row.
+//
+// Model state lives in caller-provided device scratch, one private region per chunk:
+//   IID    : K   u32 counts, initialised by the lane from the initial frequencies
+//   ORDERK : K^(k+1) u32 cells holding (count - 1); the host zero-fills the scratch (= all-ones counts,
+//            probability_models.py:110) with one hipMemsetAsync before the launch.
+#include <string.h>
+
+#include "scl_common.h"
+
+struct AecDev {
+    int kind;
+    u32 K, k;
+    u32 P, size_bits;
+    u64 max_total;
+    u64 cells;  // per-chunk scratch cells (u32)
+    u64 ctx_mod;  // K^k
+    const u32 *d_freq;  // [K] initial frequencies (FIXED / IID)
+    const u32 *d_cum;   // [K] exclusive cumulative of d_freq (FIXED)
+    u32 total0;         // sum of initial frequencies
+};
+
+struct scl_aec_model {
+    AecDev dev;
+    u32 *d_freq, *d_cum;
+};
+
+// Per-lane frequency model (one of the three kinds); `row` points at the K counts of the current context.
+struct LaneModel {
+    const AecDev *P;
+    u32 *cnt;   // private scratch (IID / ORDERK)
+    u64 ctx;    // ORDERK: flattened index of the last k symbol indices (starts at 0, :116)
+    u32 bad;    // rescale branch of the order-k model reached (raises AxisError in the reference)
+
+    __device__ __forceinline__ void init(const AecDev *P_, u32 *scratch, u64 chunk) {
+        P = P_;
+        ctx = 0;
+        bad = 0;
+        cnt = scratch ? scratch + chunk * P_->cells : nullptr;
+        if (P->kind == SCL_MODEL_IID)
+            for (u32 j = 0; j < P->K; ++j) cnt[j] = P->d_freq[j];
+    }
+    // cumulative count below s, frequency of s and total of the current distribution (freqs_current)
+    __device__ __forceinline__ void lookup(u32 s, const u32 *s_f, const u32 *s_c, u64 &c, u64 &f, u64 &T) const {
+        if (P->kind == SCL_MODEL_FIXED) {
+            c = s_c[s];
+            f = s_f[s];
+            T = P->total0;
+            return;
+        }
+        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
+        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        u64 acc = 0, cs = 0, fs = 0;
+        for (u32 j = 0; j < P->K; ++j) {
+            const u64 v = (u64)row[j] + add;
+            if (j == s) {
+                cs = acc;
+                fs = v;
+            }
+            acc += v;
+        }
+        c = cs;
+        f = fs;
+        T = acc;
+    }
+    __device__ __forceinline__ u64 total(const u32 *) const {
+        if (P->kind == SCL_MODEL_FIXED) return P->total0;
+        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
+        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        u64 acc = 0;
+        for (u32 j = 0; j < P->K; ++j) acc += (u64)row[j] + add;
+        return acc;
+    }
+    // largest s with cum[s] <= cmax; returns s and its (c, f)
+    __device__ __forceinline__ u32 search(u64 cmax, const u32 *s_f, const u32 *s_c, u64 &c, u64 &f) const {
+        if (P->kind == SCL_MODEL_FIXED) {
+            u32 lo = 0, hi = P->K;
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if ((u64)s_c[mid] <= cmax)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            c = s_c[lo];
+            f = s_f[lo];
+            return lo;
+        }
+        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
+        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        u64 acc = 0;
+        u32 j = 0;
+        for (; j + 1 < P->K; ++j) {
+            const u64 v = (u64)row[j] + add;
+            if (acc + v > cmax) break;
+            acc += v;
+        }
+        c = acc;
+        f = (u64)row[j] + add;
+        return j;
+    }
+    __device__ __forceinline__ void update(u32 s) {
+        if (P->kind == SCL_MODEL_FIXED) return;
+        if (P->kind == SCL_MODEL_IID) {  // probability_models.py:83-92
+            cnt[s] += 1;
+            u64 tot = 0;
+            for (u32 j = 0; j < P->K; ++j) tot += cnt[j];
+            if (tot >= P->max_total)
+                for (u32 j = 0; j < P->K; ++j) {
+                    const u32 h = cnt[j] >> 1;
+                    cnt[j] = h > 1 ? h : 1;
+                }
+            return;
+        }
+        // order-k, probability_models.py:143-160
+        const u64 cell = ctx * P->K + s;
+        const u32 v = cnt[cell] + 1;  // stored value is count - 1
+        cnt[cell] = v;
+        if (P->k > 0) ctx = (ctx * P->K + s) % P->ctx_mod;  // past_k[1:] + [s]
+        if ((u64)v + 1 >= P->max_total) bad = 1;  // np.max(scalar, 1) -> AxisError in the reference
+    }
+};
+
+__global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__restrict__ sym, u64 sym_stride,
+                                                        const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
+                                                        u8 *__restrict__ out, u64 out_stride,
+                                                        u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
+                                                        u32 *__restrict__ status, u32 *__restrict__ scratch) {
+    __shared__ u32 s_f[256];
+    __shared__ u32 s_c[256];
+    if (P.kind == SCL_MODEL_FIXED) {
+        scl_load_table(s_f, P.d_freq, P.K);
+        scl_load_table(s_c, P.d_cum, P.K);
+    }
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 n = lens ? lens[c] : chunk_len;
+    const u8 *src = sym + c * sym_stride;
+    const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
+    LaneModel mdl;
+    mdl.init(&P, scratch, c);
+    FwdBitWriter w;
+    w.init(out + c * out_stride, out_stride);
+    u32 st = 0;
+    if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
+    w.put(n, P.size_bits);
+    u64 low = 0, high = FULL, pending = 0;
+    for (u32 i = 0; i < n; ++i) {
+        u32 s = src[i];
+        if (s >= P.K) {
+            st |= SCL_ST_SYMBOL;
+            s = 0;
+        }
+        u64 cs, fs, T;
+        mdl.lookup(s, s_f, s_c, cs, fs, T);
+        if (T >= QTR) {  // assert total_freq < MAX_ALLOWED_TOTAL_FREQ, arithmetic_coding.py:110-112
+            st |= SCL_ST_TOTAL;
+            break;
+        }
+        const u64 rng = high - low;  // shrink_range :70-77
+        high = low + (rng * (cs + fs)) / T;
+        low = low + (rng * cs) / T;
+        mdl.update(s);  // :118
+        while (high < HALF || low > HALF) {  // E1 / E2, :126-143
+            if (high < HALF) {
+                w.put(0, 1);
+                w.put_run(1, pending);
+                low <<= 1;
+                high <<= 1;
+            } else {
+                w.put(1, 1);
+                w.put_run(0, pending);
+                low = (low - HALF) << 1;
+                high = (high - HALF) << 1;
+            }
+            pending = 0;
+        }
+        while (low > QTR && high < 3 * QTR) {  // E3, :146-150
+            pending += 1;
+            low = (low - QTR) << 1;
+            high = (high - QTR) << 1;
+        }
+    }
+    pending += 1;  // termination, :153-159
+    if (low <= QTR) {
+        w.put(0, 1);
+        w.put_run(1, pending);
+    } else {
+        w.put(1, 1);
+        w.put_run(0, pending);
+    }
+    if (mdl.bad) st |= SCL_ST_TOTAL;
+    const u64 total = w.finish();
+    if (w.overflow) st |= SCL_ST_CAPACITY;
+    out_bit_off[c] = c * out_stride * 8;
+    out_nbits[c] = (u32)total;
+    if (status) status[c] = st;
+}
+
+__global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__restrict__ in, u64 in_size_bytes,
+                                                        const u64 *__restrict__ bit_off,
+                                                        const u32 *__restrict__ in_nbits, u64 n_chunks,
+                                                        u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
+                                                        u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
+                                                        u32 *__restrict__ status, u32 *__restrict__ scratch) {
+    __shared__ u32 s_f[256];
+    __shared__ u32 s_c[256];
+    if (P.kind == SCL_MODEL_FIXED) {
+        scl_load_table(s_f, P.d_freq, P.K);
+        scl_load_table(s_c, P.d_cum, P.K);
+    }
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
+    BitReader r;
+    r.init(in, in_size_bytes, bit_off[c], in_nbits[c]);
+    u32 st = 0;
+    u32 n = r.get(P.size_bits);
+    if (r.truncated) {
+        st |= SCL_ST_TRUNCATED;
+        n = 0;
+    }
+    out_lens[c] = n;
+    if (n > out_cap) {
+        st |= SCL_ST_CAPACITY;
+        n = 0;
+    }
+    if (n == 0) {  // quirk Q5: defined here as header + the encoder's two termination bits
+        consumed[c] = (st == 0) ? P.size_bits + 2 : 0;
+        if (status) status[c] = st;
+        return;
+    }
+    LaneModel mdl;
+    mdl.init(&P, scratch, c);
+    u8 *dst = out_sym + c * out_stride;
+    // bit positions relative to the first bit after the header; bits past the end read as 0 (:258-261)
+    const u64 body = r.pos;
+    u64 used = P.P;  // the state register is always filled with PRECISION bits (:222-229)
+    u64 state = r.peek_at(body, P.P);
+    u64 low = 0, high = FULL;
+    u32 ndec = 0;
+    for (;;) {
+        const u64 T = mdl.total(s_f);
+        if (T >= QTR) {
+            st |= SCL_ST_TOTAL;
+            break;
+        }
+        const u64 rng = high - low;
+        const u64 cmax = ((state - low + 1) * T - 1) / rng;  // see file header
+        u64 cs, fs;
+        const u32 s = mdl.search(cmax, s_f, s_c, cs, fs);
+        high = low + (rng * (cs + fs)) / T;
+        low = low + (rng * cs) / T;
+        dst[ndec++] = (u8)s;
+        mdl.update(s);
+        if (ndec == n) break;  // before the renormalisation, :242-243
+        while (high < HALF || low > HALF) {
+            if (high < HALF) {
+                low <<= 1;
+                high <<= 1;
+                state <<= 1;
+            } else {
+                low = (low - HALF) << 1;
+                high = (high - HALF) << 1;
+                state = (state - HALF) << 1;
+            }
+            state += r.peek_at(body + used, 1);
+            used++;
+        }
+        while (low > QTR && high < 3 * QTR) {
+            low = (low - QTR) << 1;
+            high = (high - QTR) << 1;
+            state = (state - QTR) << 1;
+            state += r.peek_at(body + used, 1);
+            used++;
+        }
+    }
+    // how many of the last PRECISION bits belonged to the encoder (:277-282)
+    u32 e = 0;
+    for (; e < P.P; ++e) {
+        const u64 slo = (state >> e) << e, shi = slo + (1ull << e);
+        if (slo < low || shi > high) break;
+    }
+    if (e == P.P) e = P.P - 1;  // Python's loop variable after an unbroken range(PRECISION)
+    if (mdl.bad) st |= SCL_ST_TOTAL;
+    consumed[c] = (u32)((i64)(used + P.size_bits) - ((i64)e - 1));
+    if (status) status[c] = st;
+}
+
+// ---- host API -------------------------------------------------------------------------------------------
+extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init, uint32_t K, uint32_t order_k,
+                                    uint64_t max_total, uint32_t precision, uint32_t size_bits, scl_aec_model **out) {
+    SCL_REQUIRE(out, "aec_model_create: null output");
+    *out = nullptr;
+    SCL_REQUIRE(model_kind == SCL_MODEL_FIXED || model_kind == SCL_MODEL_IID || model_kind == SCL_MODEL_ORDERK,
+                "aec_model_create: unknown model kind %d", model_kind);
+    SCL_REQUIRE(K >= 1 && K <= 256, "aec_model_create: alphabet size %u outside 1..256", K);
+    SCL_REQUIRE(precision >= 8 && precision <= 32, "aec_model_create: PRECISION %u outside 8..32", precision);
+    SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "aec_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32", size_bits);
+    SCL_REQUIRE(max_total >= 2, "aec_model_create: max_allowed_total_freq too small");
+    scl_aec_model *m = new scl_aec_model();
+    m->dev.kind = model_kind;
+    m->dev.K = K;
+    m->dev.k = 0;
+    m->dev.P = precision;
+    m->dev.size_bits = size_bits;
+    m->dev.max_total = max_total;
+    m->dev.ctx_mod = 1;
+    m->dev.cells = 0;
+    u32 freq[256], cum[256];
+    u64 tot = 0;
+    if (model_kind == SCL_MODEL_ORDERK) {
+        if (order_k > 3) {
+            delete m;
+            scl_set_error("aec_model_create: order k = %u > 3 not supported", order_k);
+            return SCL_E_PARAM;
+        }
+        m->dev.k = order_k;
+        u64 cells = K;
+        for (u32 i = 0; i < order_k; ++i) {
+            m->dev.ctx_mod *= K;
+            cells *= K;
+        }
+        if (cells > (1ull << 26)) {
+            delete m;
+            scl_set_error("aec_model_create: K^(k+1) = %llu cells per chunk is too large", (unsigned long long)cells);
+            return SCL_E_PARAM;
+        }
+        m->dev.cells = cells;
+        for (u32 i = 0; i < K; ++i) {
+            freq[i] = 1;
+            cum[i] = i;
+        }
+        tot = K;
+    } else {
+        if (!h_freq_init) {
+            delete m;
+            scl_set_error("aec_model_create: initial frequencies required");
+            return SCL_E_PARAM;
+        }
+        for (u32 i = 0; i < K; ++i) {
+            if (h_freq_init[i] == 0 || tot + h_freq_init[i] >= (1ull << 32)) {
+                delete m;
+                scl_set_error("aec_model_create: zero or too large initial frequency at symbol %u", i);
+                return SCL_E_PARAM;
+            }
+            freq[i] = h_freq_init[i];
+            cum[i] = (u32)tot;
+            tot += h_freq_init[i];
+        }
+        m->dev.cells = (model_kind == SCL_MODEL_IID) ? K : 0;
+    }
+    m->dev.total0 = (u32)tot;
+    hipError_t e = hipMalloc((void **)&m->d_freq, 256 * sizeof(u32));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
+    if (e == hipSuccess) e = hipMemcpy(m->d_freq, freq, K * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        scl_set_error("aec_model_create: device table upload failed: %s", hipGetErrorString(e));
+        scl_aec_model_destroy(m);
+        return SCL_E_HIP;
+    }
+    m->dev.d_freq = m->d_freq;
+    m->dev.d_cum = m->d_cum;
+    *out = m;
+    return SCL_OK;
+}
+
+extern "C" void scl_aec_model_destroy(scl_aec_model *m) {
+    if (!m) return;
+    if (m->d_freq) (void)hipFree(m->d_freq);
+    if (m->d_cum) (void)hipFree(m->d_cum);
+    delete m;
+}
+
+extern "C" uint64_t scl_aec_slot_bytes(const scl_aec_model *m, uint64_t n_symbols) {
+    if (!m) return 0;
+    // every symbol narrows the interval by at most a factor 1/QTR-ish: <= PRECISION bits per symbol, plus
+    // header, termination and pending bits
+    const u64 bits = (u64)m->dev.size_bits + n_symbols * (u64)m->dev.P + 2 * m->dev.P + 8;
+    return scl_round_up((bits + 7) / 8 + 4, 16);
+}
+
+extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chunks) {
+    if (!m) return 0;
+    return scl_round_up(m->dev.cells * n_chunks * sizeof(u32), 256);
+}
+
+static int aec_prepare_scratch(const scl_aec_model *m, u64 n_chunks, void *d_scratch, u64 scratch_bytes,
+                               hipStream_t st) {
+    const u64 need = m->dev.cells * n_chunks * sizeof(u32);
+    SCL_REQUIRE(need == 0 || (d_scratch && scratch_bytes >= need), "aec: scratch of %llu bytes required, got %llu",
+                (unsigned long long)need, (unsigned long long)scratch_bytes);
+    if (m->dev.kind == SCL_MODEL_ORDERK) SCL_HIP_TRY(hipMemsetAsync(d_scratch, 0, need, st));
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                    const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks, uint8_t *d_out,
+                                    uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
+                                    uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes, void *stream) {
+    SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "aec_encode_batch: null pointer argument");
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
+                "aec_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "aec_encode_batch: d_out must be 16-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+    if (rc) return rc;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    hipLaunchKernelGGL(aec_encode_kernel, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride, d_lens,
+                       chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
+                       (u32 *)d_scratch);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                    const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
+                                    uint8_t *d_out_sym, uint64_t out_stride, uint32_t out_cap, uint32_t *d_out_lens,
+                                    uint32_t *d_consumed, uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes,
+                                    void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "aec_decode_batch: null pointer argument");
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+    if (rc) return rc;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    hipLaunchKernelGGL(aec_decode_kernel, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                       d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                       d_status, (u32 *)d_scratch);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+// ---- single-chunk host drivers --------------------------------------------------------------------------
+static int aec_run_enc(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                       u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_encode_batch((const scl_aec_model *)model, d_sym, n, nullptr, n, 1, d_out, out_stride, d_bit_off,
+                                d_nbits, d_status, d_scratch, scratch_bytes, nullptr);
+}
+static u64 aec_slot(const void *model, u64 n) { return scl_aec_slot_bytes((const scl_aec_model *)model, n); }
+static u64 aec_scratch(const void *model) { return scl_aec_scratch_bytes((const scl_aec_model *)model, 1); }
+static int aec_run_dec(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
+                       u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *d_scratch,
+                       u64 scratch_bytes) {
+    return scl_aec_decode_batch((const scl_aec_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1, d_out_sym,
+                                scl_round_up((u64)out_cap + 1, 16), out_cap, d_out_len, d_consumed, d_status,
+                                d_scratch, scratch_bytes, nullptr);
+}
+
+extern "C" int scl_aec_encode_host(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                                   uint64_t out_cap_bytes, uint64_t *nbits) {
+    HostEncodeCall call = {aec_run_enc, aec_slot, aec_scratch};
+    return scl_host_encode_one(call, m, h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_aec_decode_host(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits, uint8_t *h_out_sym,
+                                   uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
+    HostDecodeCall call = {aec_run_dec, aec_scratch};
+    return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *
     u8 *dst = out_sym + c * out_stride;
     const u32 b = P.b;
     const ST M = (ST)P.M, L = (ST)P.L;
+    const u32 st_header = st;
     for (u32 i = n; i-- > 0;) {
         // rans_base_decode_step :234-249
         ST block_id, slot;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *
         if (r.truncated) break;
     }
     if (r.truncated) st |= SCL_ST_TRUNCATED;
-    else if (x != L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE, :295
+    else if (st_header == 0 && x != L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE, :295
     consumed[c] = (u32)(r.pos - start);
     if (status) status[c] = st;
 }

@@ -1,0 +1,97 @@
+"""GPU parity, part 1: the drop-in Encoder/Decoder classes (C ABI host entry points -> HIP kernels) against
+the reference-generated golden vectors: encoder bits, decoder symbols and num_bits_consumed with 0/3/61
+trailing garbage bits.  Bit-exact (integer/bit work: no tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import golden_ids, load_golden
+from stanford_compression_library_amd.compressors.arithmetic_coding import (AECParams, ArithmeticDecoder,
+                                                                             ArithmeticEncoder)
+from stanford_compression_library_amd.compressors.probability_models import (AdaptiveIIDFreqModel,
+                                                                               AdaptiveOrderKFreqModel,
+                                                                               FixedFreqModel)
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.prob_dist import Frequencies
+from stanford_compression_library_amd.utils.bitarray_utils import BitArray
+
+pytestmark = pytest.mark.gpu
+
+RANS = load_golden("rans")
+TANS = [c for c in load_golden("tans") if c.kind == "tans"]
+TANS_TABLES = [c for c in load_golden("tans") if c.kind == "tans_tables"]
+RANGE = load_golden("range")
+AEC = load_golden("aec")
+
+
+def _alphabet(K):
+    # string symbols: exercises the symbol -> index mapping of the class API
+    return [f"s{i}" for i in range(K)]
+
+
+def _check(case, encoder, make_decoder, alphabet):
+    block = DataBlock([alphabet[i] for i in case.arr("sym").tolist()])
+    bits = encoder.encode_block(block)
+    assert isinstance(bits, BitArray)
+    assert len(bits) == case.nbits
+    assert np.array_equal(bits.packed(), case.arr("out"))
+    for packed, total, used in case.bits_with_garbage:
+        decoded, got_used = make_decoder().decode_block(BitArray.from_packed(packed, total))
+        assert got_used == used
+        assert decoded.data_list == block.data_list
+
+
+@pytest.mark.parametrize("case", RANS, ids=golden_ids(RANS))
+def test_rans(case):
+    alphabet = _alphabet(len(case.freq))
+    p = rANSParams(Frequencies(dict(zip(alphabet, case.freq))), DATA_BLOCK_SIZE_BITS=case.size_bits,
+                   NUM_BITS_OUT=case.b, RANGE_FACTOR=case.RF)
+    _check(case, rANSEncoder(p), lambda: rANSDecoder(p), alphabet)
+
+
+@pytest.mark.parametrize("case", TANS, ids=golden_ids(TANS))
+def test_tans(case):
+    alphabet = _alphabet(len(case.freq))
+    p = tANSParams(Frequencies(dict(zip(alphabet, case.freq))), DATA_BLOCK_SIZE_BITS=case.size_bits,
+                   RANGE_FACTOR=case.RF)
+    _check(case, tANSEncoder(p), lambda: tANSDecoder(p), alphabet)
+
+
+@pytest.mark.parametrize("case", TANS_TABLES, ids=golden_ids(TANS_TABLES))
+def test_tans_tables(case):
+    """the five lookup tables, compared as dicts like the reference's own test (tANS.py:285-337)"""
+    alphabet = ["A", "B", "C"]
+    p = tANSParams(Frequencies(dict(zip(alphabet, case.freq))), RANGE_FACTOR=case.RF, NUM_BITS_OUT=1,
+                   DATA_BLOCK_SIZE_BITS=5)
+    enc, dec = tANSEncoder(p), tANSDecoder(p)
+    assert enc.base_encode_step_table == {(alphabet[s], xs): v for s, xs, v in case.arr("enc_tab").tolist()}
+    assert dec.base_decode_step_table == {x: (alphabet[s], xs) for x, s, xs in case.arr("dec_tab").tolist()}
+    assert enc.shrink_state_num_out_bits_base_table == dict(zip(alphabet, case.arr("nbits_tab").tolist()))
+    assert enc.shrink_state_thresh_table == dict(zip(alphabet, case.arr("thresh_tab").tolist()))
+    assert dec.expand_state_num_bits_table == {xs: nb for xs, nb in case.arr("expand_tab").tolist()}
+
+
+@pytest.mark.parametrize("case", RANGE, ids=golden_ids(RANGE))
+def test_range(case):
+    alphabet = _alphabet(len(case.freq))
+    fr = Frequencies(dict(zip(alphabet, case.freq)))
+    p = RangeCoderParams(DATA_BLOCK_SIZE_BITS=case.size_bits, PRECISION=case.precision)
+    _check(case, RangeEncoder(p, fr), lambda: RangeDecoder(p, fr), alphabet)
+
+
+def _freq_model(case, alphabet):
+    if case.model == "orderk":
+        return AdaptiveOrderKFreqModel(alphabet, case.k, case.max_total)
+    fr = Frequencies(dict(zip(alphabet, case.freq)))
+    cls = FixedFreqModel if case.model == "fixed" else AdaptiveIIDFreqModel
+    return cls(fr, case.max_total)
+
+
+@pytest.mark.parametrize("case", AEC, ids=golden_ids(AEC))
+def test_aec(case):
+    alphabet = _alphabet(case.K)
+    p = AECParams(DATA_BLOCK_SIZE_BITS=case.size_bits, PRECISION=case.precision)
+    _check(case, ArithmeticEncoder(p, _freq_model(case, alphabet)),
+           lambda: ArithmeticDecoder(p, _freq_model(case, alphabet)), alphabet)

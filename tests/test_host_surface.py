@@ -1,0 +1,154 @@
+"""Host-side surface of the path (no GPU): BitArray, DataBlock, Frequencies, the params dataclasses and the
+frequency-model mirrors behave like the reference's (values below were produced by the imported reference)."""
+import copy
+
+import numpy as np
+import pytest
+
+from stanford_compression_library_amd.compressors.arithmetic_coding import AECParams
+from stanford_compression_library_amd.compressors.probability_models import (AdaptiveIIDFreqModel,
+                                                                               AdaptiveOrderKFreqModel,
+                                                                               FixedFreqModel)
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.prob_dist import Frequencies, ProbabilityDist, get_avg_neg_log_prob
+from stanford_compression_library_amd.utils.bitarray_utils import (BitArray, bitarray_to_uint, get_bit_width,
+                                                                     get_random_bitarray, uint_to_bitarray)
+from stanford_compression_library_amd.utils.test_utils import get_random_data_block
+
+
+# ---- BitArray (operations listed in SURVEY.md 8b) ---------------------------------------------------
+def test_bitarray_construct_and_compare():
+    a = BitArray("0101")
+    assert len(a) == 4 and a.tolist() == [0, 1, 0, 1] and a.to01() == "0101"
+    assert BitArray(a) == a and BitArray(a) is not a
+    assert len(BitArray("")) == 0 and len(BitArray()) == 0
+    assert BitArray("01") != BitArray("010")
+    with pytest.raises(ValueError):
+        BitArray("012")
+
+
+def test_bitarray_concat_slice_index_iter():
+    a, b = BitArray("110"), BitArray("01")
+    assert (a + b).to01() == "11001"
+    c = BitArray(a)
+    c += b
+    assert c.to01() == "11001" and a.to01() == "110"
+    assert c[1:4].to01() == "100" and c[:2].to01() == "11" and c[3:].to01() == "01" and c[-2:].to01() == "01"
+    assert c[0] == 1 and c[2] == 0 and list(c) == [1, 1, 0, 0, 1]
+    c.extend("011")
+    assert c.to01() == "11001011"
+
+
+def test_bitarray_bytes_roundtrip_is_msb_first_zero_padded():
+    a = BitArray()
+    a.frombytes(bytes([0xA5, 0x01]))
+    assert a.to01() == "1010010100000001"
+    assert BitArray("101").tobytes() == bytes([0b10100000])
+    assert BitArray("").tobytes() == b""
+    assert BitArray.from_packed(bytes([0b00010110, 0xFF]), 5, bit_offset=3).to01() == "10110"
+
+
+def test_uint_conversions_and_bit_width():
+    assert uint_to_bitarray(5, 5).to01() == "00101"
+    assert uint_to_bitarray(0).to01() == "0" and uint_to_bitarray(6).to01() == "110"
+    assert uint_to_bitarray(np.int64(11), 4).to01() == "1011"
+    assert bitarray_to_uint(BitArray("00011")) == 3
+    with pytest.raises(OverflowError):
+        uint_to_bitarray(16, 4)
+    for x in (0, 1, 2, 3, 4, 255, 256, (1 << 29) - 1, 1 << 29, (1 << 62) + 5):
+        assert bitarray_to_uint(uint_to_bitarray(x)) == x
+    assert [get_bit_width(x) for x in (0, 1, 2, 3, 4, 15, 16, 655359)] == [1, 1, 2, 2, 3, 4, 5, 20]
+    assert len(get_random_bitarray(77)) == 77
+
+
+# ---- DataBlock / Frequencies / ProbabilityDist --------------------------------------------------------
+def test_data_block():
+    blk = DataBlock([0, 1, 0, 0, 1, 1])
+    assert blk.size == 6 and blk.get_counts()[0] == 3 and blk.get_alphabet() == {0, 1}
+    assert blk.get_empirical_distribution().prob_dict[0] == 0.5 and blk.get_entropy() == 1.0
+    with pytest.raises(NotImplementedError):
+        blk.get_counts(order=1)
+
+
+def test_frequencies_keep_insertion_order():
+    fr = Frequencies({"C": 2, "A": 3, "B": 3})
+    assert fr.alphabet == ["C", "A", "B"] and fr.freq_list == [2, 3, 3] and fr.total_freq == 8 and fr.size == 3
+    assert fr.cumulative_freq_dict == {"C": 0, "A": 2, "B": 5} and fr.frequency("A") == 3
+    f, c = fr.index_tables()
+    assert f.tolist() == [2, 3, 3] and c.tolist() == [0, 2, 5]
+    assert fr.get_prob_dist().prob_dict == {"C": 0.25, "A": 0.375, "B": 0.375}
+    with pytest.raises(KeyError):
+        fr.frequency("Z")
+
+
+def test_probability_dist_and_data_generation():
+    pd = ProbabilityDist({"A": 0.5, "B": 0.25, "C": 0.25})
+    assert pd.entropy == 1.5 and pd.neg_log_probability("B") == 2.0
+    assert pd.cumulative_prob_dict == {"A": 0, "B": 0.5, "C": 0.75}
+    with pytest.raises(ValueError):
+        ProbabilityDist({"A": 0.5, "B": 0.4})
+    blk = get_random_data_block(Frequencies({0: 1, 1: 4}).get_prob_dist(), 4096, seed=0)
+    # sha256 of the reference's block for this seed
+    import hashlib
+
+    assert hashlib.sha256(bytes(blk.data_list)).hexdigest()[:16] == "1e7226b7760e9d47"
+    assert abs(get_avg_neg_log_prob(Frequencies({0: 1, 1: 4}).get_prob_dist(), blk) - 0.7275) < 0.02
+
+
+# ---- params dataclasses --------------------------------------------------------------------------------
+def test_rans_params_derived_values():
+    p = rANSParams(Frequencies({"A": 3, "B": 3, "C": 2}), DATA_BLOCK_SIZE_BITS=5, NUM_BITS_OUT=1, RANGE_FACTOR=1)
+    assert (p.M, p.L, p.H, p.INITIAL_STATE, p.NUM_STATE_BITS) == (8, 8, 15, 8, 4)
+    assert p.min_shrunk_state == {"A": 3, "B": 3, "C": 2} and p.max_shrunk_state == {"A": 5, "B": 5, "C": 3}
+    d = rANSParams(Frequencies({0: 1, 1: 4}))
+    assert (d.M, d.L, d.H, d.NUM_STATE_BITS, d.DATA_BLOCK_SIZE_BITS, d.NUM_BITS_OUT) == (5, 327680, 655359, 20, 32, 1)
+    with pytest.raises(AssertionError):
+        rANSParams(Frequencies({0: 1}), NUM_BITS_OUT=32, RANGE_FACTOR=1 << 40)
+
+
+def test_tans_params_asserts():
+    tANSParams(Frequencies({"A": 1, "B": 3}), RANGE_FACTOR=4)
+    with pytest.raises(AssertionError):
+        tANSParams(Frequencies({"A": 1, "B": 2}))
+    with pytest.raises(AssertionError):
+        tANSParams(Frequencies({"A": 1, "B": 3}), NUM_BITS_OUT=2)
+
+
+def test_range_and_aec_params():
+    r = RangeCoderParams()
+    assert (r.TOP, r.BOTTOM, r.MASK) == (1 << 24, 1 << 16, (1 << 32) - 1)
+    with pytest.raises(AssertionError):
+        RangeCoderParams(PRECISION=20)
+    with pytest.raises(AssertionError):
+        RangeEncoder(RangeCoderParams(), Frequencies({"A": 1, "B": 65536}))
+    with pytest.raises(AssertionError):
+        RangeEncoder(RangeCoderParams(), Frequencies({"A": 0, "B": 5}))
+    a = AECParams(PRECISION=16)
+    assert (a.FULL, a.HALF, a.QTR, a.MAX_ALLOWED_TOTAL_FREQ, a.MAX_BLOCK_SIZE) == (65536, 32768, 16384, 16384, 1 << 32)
+
+
+# ---- frequency-model host mirrors ----------------------------------------------------------------------
+def test_freq_models_host_mirror():
+    fr = Frequencies({"A": 2, "B": 1})
+    fixed = FixedFreqModel(fr, 1 << 30)
+    fixed.update_model("A")
+    assert fixed.freqs_current.freq_dict == {"A": 2, "B": 1} and fixed.device_spec()["kind"] == 0
+    iid = AdaptiveIIDFreqModel(fr, 8)
+    for s in "AAAA":
+        iid.update_model(s)
+    assert iid.freqs_current.freq_dict == {"A": 6, "B": 1}
+    iid.update_model("B")  # total reaches 8 -> halve with floor 1
+    assert iid.freqs_current.freq_dict == {"A": 3, "B": 1}
+    assert fr.freq_dict == {"A": 2, "B": 1}  # the model works on a copy
+    assert iid.device_spec()["freq_init"] == [2, 1]  # the device starts every chunk from the initial table
+    ok = AdaptiveOrderKFreqModel([0, 1, 2], 1, 1 << 30)
+    assert ok.freqs_current.freq_dict == {0: 1, 1: 1, 2: 1}
+    ok.update_model(2)
+    assert ok.past_k == [2] and ok.freqs_kplus1_tuple[0, 2] == 2
+    ok.update_model(1)
+    assert ok.freqs_kplus1_tuple[2, 1] == 2 and ok.freqs_current.freq_dict == {0: 1, 1: 1, 2: 1}
+    spec = copy.deepcopy(ok).device_spec()
+    assert (spec["kind"], spec["K"], spec["k"]) == (2, 3, 1)
