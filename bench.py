@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X entropy-coding core.
+
+Metric (BASELINE.json): MB/s encode+decode of 1 GiB i.i.d. bytes with 256-symbol static rANS
+(reference defaults NUM_BITS_OUT=1, RANGE_FACTOR=2^16, M=4096), plus achieved HBM GB/s vs peak.
+
+One "step" = one full encode pass + one full decode pass over the per-GPU batch
+(262 144 chunks x 4 KiB = 1 GiB, one wavefront lane per chunk), inputs resident in HBM.
+value = (bytes of all ranks * steps) / wall time of the timed region / 1e6, i.e. N / (t_enc + t_dec).
+
+    python bench.py                      # 1 GPU, finishes in a few minutes incl. the CPU baseline
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: chunks are independent, so every rank encodes/decodes its own 1 GiB shard (weak scaling,
+no data-path collective); the only communication is the barrier / max-reduction of the timing.
+`--gather` additionally times the optional final gather of the compacted streams to rank 0
+(BASELINE.json configs[4]) and reports it separately; it never enters `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chunks", type=int, default=262144, help="chunks per GPU")
+    ap.add_argument("--chunk-len", type=int, default=4096)
+    ap.add_argument("--table", choices=["t256", "uniform"], default="t256")
+    ap.add_argument("--coder", choices=["rans", "tans", "range"], default="rans")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
+    return ap.parse_args()
+
+
+def make_model(args, freq):
+    from stanford_compression_library_amd.backend import models
+
+    if args.coder == "rans":
+        return models.RansModel(freq.tolist(), 1 << 16, 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1 << 16)
+    if args.coder == "tans":
+        return models.TansModel(freq.tolist(), 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1)
+    return models.RangeModel(freq.tolist(), 32, 32), dict(PRECISION=32)
+
+
+def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
+    """Times the CPU oracle (C restatement, one thread) on a bounded sample of the SAME workload and, as a
+    by-product, checks the GPU streams of those chunks bit-for-bit against it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import scl_oracle as orc
+
+    if args.coder != "rans":
+        return None
+    n_probe = min(128, sym_dev.shape[0])
+    sym = sym_dev[:n_probe].cpu().numpy()
+    t0 = time.perf_counter()
+    streams, nbits = orc.rans_encode_batch(sym, freq)
+    orc.rans_decode_batch(streams, nbits, freq, sym.shape[1])
+    per_chunk = (time.perf_counter() - t0) / n_probe
+    n = int(max(n_probe, min(sym_dev.shape[0], target_seconds / max(per_chunk, 1e-9))))
+    sym = sym_dev[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    streams, nbits = orc.rans_encode_batch(sym, freq)
+    t1 = time.perf_counter()
+    dec, used = orc.rans_decode_batch(streams, nbits, freq, sym.shape[1])
+    t2 = time.perf_counter()
+    assert np.array_equal(dec, sym) and np.array_equal(used, nbits)
+    # parity by-product: GPU streams of the sampled chunks == oracle streams
+    g_nbits = enc.nbits[:n].cpu().numpy().astype(np.uint64)
+    assert np.array_equal(g_nbits, nbits), "GPU/oracle stream lengths differ"
+    data = enc.data.cpu().numpy() if n * enc.stride < (1 << 31) else None
+    if data is not None:
+        offs = enc.bit_offset[:n].cpu().numpy()
+        for c in range(0, n, max(1, n // 64)):
+            nb = int(nbits[c])
+            got = np.unpackbits(data[int(offs[c]) // 8:(int(offs[c]) + nb + 7) // 8 + 1])
+            lo = int(offs[c]) % 8
+            assert np.array_equal(got[lo:lo + nb], np.unpackbits(streams[c])[:nb]), f"chunk {c}: GPU != oracle"
+    nbytes = sym.size
+    return {
+        "value": round(nbytes / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+        "sample": f"{n} chunks x {sym.shape[1]} B of the same batch ({nbytes / 2**20:.1f} MiB), oracle/scl_oracle.c "
+                  f"-O2 single thread, encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode {nbytes / (t2 - t1) / 1e6:.2f} MB/s",
+        "encode_MBps": round(nbytes / (t1 - t0) / 1e6, 3), "decode_MBps": round(nbytes / (t2 - t1) / 1e6, 3),
+        "gpu_streams_checked_against_oracle": True,
+    }
+
+
+def load_traffic_note():
+    """HBM traffic per launch measured with rocprofv3 PMC passes (committed under profiles/)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from stanford_compression_library_amd import bench_data
+    from stanford_compression_library_amd.backend import lib
+
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)))
+        world = dist.get_world_size()
+    lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    freq = bench_data.t256_table() if args.table == "t256" else bench_data.uniform256_table()
+    model, coder_params = make_model(args, freq)
+    n_chunks, chunk_len = args.chunks, args.chunk_len
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
+    enc = model.alloc_encoded(n_chunks, chunk_len, dev)
+    dec_out = model.alloc_decoded(n_chunks, chunk_len, dev)
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        model.encode_batch(sym, out=enc)
+        if events is not None:
+            events[1].record()
+        model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec_out)
+        if events is not None:
+            events[2].record()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(evs[i])  # events sit on torch's current stream, the stream the kernels are launched on
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was just timed (outside the timed region) ------------------------------
+    dec_sym, dec_lens, dec_used, dec_status = dec_out
+    ok = (int(enc.status.abs().sum()) == 0 and int(dec_status.abs().sum()) == 0
+          and torch.equal(dec_sym[:, :chunk_len], sym) and torch.equal(dec_used, enc.nbits)
+          and int(dec_lens.min()) == chunk_len and int(dec_lens.max()) == chunk_len)
+    if not ok:
+        raise SystemExit(f"rank {rank}: round trip FAILED (status enc={int(enc.status.abs().sum())} "
+                         f"dec={int(dec_status.abs().sum())})")
+
+    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    in_bytes = n_chunks * chunk_len
+    stream_bytes = int(((enc.nbits.to(torch.int64) + 7) // 8).sum().item())
+    alg_bytes = in_bytes + stream_bytes  # encode = n read + ceil(bits/8) written (decode mirrors it)
+    bits_per_symbol = float(enc.nbits.to(torch.float64).mean().item()) / chunk_len
+
+    gather_info = None
+    if args.gather:
+        from stanford_compression_library_amd.backend.sharded import gather_streams_to_root
+        from stanford_compression_library_amd.backend.models import compact
+
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        dense, offsets = compact(enc)
+        torch.cuda.synchronize()
+        g1 = time.perf_counter()
+        total = gather_streams_to_root(dense, offsets, world, rank, dev) if world > 1 else int(offsets[-1])
+        torch.cuda.synchronize()
+        barrier()
+        g2 = time.perf_counter()
+        gather_info = {"compact_ms": round((g1 - g0) * 1e3, 3), "gather_ms": round((g2 - g1) * 1e3, 3),
+                       "gathered_bytes": int(total)}
+
+    if rank == 0:
+        total_bytes = in_bytes * world
+        value = total_bytes * args.steps / elapsed / 1e6
+        traffic = load_traffic_note()
+
+        def roof(ms, name):
+            gbs = alg_bytes / (ms * 1e-3) / 1e9
+            t = traffic.get(name) if traffic else None
+            return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": t,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4),
+                    "read_only_frac": round(in_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if "encode" in name else None}
+
+        r_enc, r_dec = roof(enc_ms, f"{args.coder}_encode"), roof(dec_ms, f"{args.coder}_decode")
+        out = {
+            "metric": "MB/s encode+decode, 1 GiB i.i.d. bytes, 256-sym rANS; achieved HBM GB/s %peak",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"batched 256-symbol static-model {args.coder}: {n_chunks} independent "
+                                   f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
+                                   f"table {args.table} (M=4096), i.i.d. symbols p=f/M",
+                       "coder": args.coder, **coder_params, "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
+                       "bits_per_symbol_out": round(bits_per_symbol, 4), "sharding": f"{world} x independent shards"},
+            "encode_MBps": round(total_bytes / (enc_ms * 1e-3) / 1e6, 2),
+            "decode_MBps": round(total_bytes / (dec_ms * 1e-3) / 1e6, 2),
+            "roofline": r_enc if enc_ms >= dec_ms else r_dec,
+            "roofline_encode": r_enc, "roofline_decode": r_dec,
+            "round_trip_verified": True,
+        }
+        if gather_info:
+            out["gather"] = gather_info
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, freq, sym, enc)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,18 +101,29 @@ class _DeviceModel:
             return None, 0
         return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
-    def encode_batch(self, sym, lens=None, out_stride: Optional[int] = None, stream=None) -> EncodedBatch:
-        """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks]."""
+    def alloc_encoded(self, n_chunks: int, chunk_len: int, device, out_stride: Optional[int] = None) -> EncodedBatch:
+        """Output buffers of a batched encode (reusable across calls of the same shape)."""
+        import torch
+
+        stride = int(out_stride or self.slot_bytes(chunk_len))
+        return EncodedBatch(torch.empty(n_chunks * stride + 16, dtype=torch.uint8, device=device), stride,
+                            torch.empty(n_chunks, dtype=torch.int64, device=device),
+                            torch.empty(n_chunks, dtype=torch.int32, device=device),
+                            torch.empty(n_chunks, dtype=torch.int32, device=device), n_chunks)
+
+    def encode_batch(self, sym, lens=None, out_stride: Optional[int] = None, stream=None,
+                     out: Optional[EncodedBatch] = None) -> EncodedBatch:
+        """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks].
+        ``out`` reuses buffers from :meth:`alloc_encoded`."""
         import torch
 
         assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
-        stride = int(out_stride or self.slot_bytes(chunk_len))
         dev = sym.device
-        data = torch.empty(n_chunks * stride + 16, dtype=torch.uint8, device=dev)
-        bit_off = torch.empty(n_chunks, dtype=torch.int64, device=dev)
-        nbits = torch.empty(n_chunks, dtype=torch.int32, device=dev)
-        status = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        if out is None:
+            out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride)
+        assert out.n_chunks == n_chunks
+        stride, data, bit_off, nbits, status = out.stride, out.data, out.bit_offset, out.nbits, out.status
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         args = [self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None,
                 chunk_len, n_chunks, data.data_ptr(), stride, bit_off.data_ptr(), nbits.data_ptr(),
@@ -123,20 +134,27 @@ class _DeviceModel:
             self._last_scratch = scratch  # keep alive until the stream is done
         rc = self._fn("encode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
-        return EncodedBatch(data, stride, bit_off, nbits, status, n_chunks)
+        return out
 
-    def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None):
-        """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device."""
+    def alloc_decoded(self, n_chunks: int, chunk_cap: int, device):
+        import torch
+
+        out_stride = (int(chunk_cap) + 15) // 16 * 16
+        return (torch.empty((n_chunks, out_stride), dtype=torch.uint8, device=device),
+                torch.empty(n_chunks, dtype=torch.int32, device=device),
+                torch.empty(n_chunks, dtype=torch.int32, device=device),
+                torch.empty(n_chunks, dtype=torch.int32, device=device))
+
+    def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None, out=None):
+        """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device.
+        ``out`` reuses buffers from :meth:`alloc_decoded`."""
         import torch
 
         assert data.is_cuda and data.dtype == torch.uint8
         n_chunks = int(bit_offset.numel())
         dev = data.device
-        out_stride = (int(chunk_cap) + 15) // 16 * 16
-        sym = torch.empty((n_chunks, out_stride), dtype=torch.uint8, device=dev)
-        lens = torch.empty(n_chunks, dtype=torch.int32, device=dev)
-        used = torch.empty(n_chunks, dtype=torch.int32, device=dev)
-        status = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+        sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
+        out_stride = sym.stride(0)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         args = [self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
                 sym.data_ptr(), out_stride, int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr()]

@@ -41,8 +41,8 @@ class _RangeBase:
     def _device_model(self) -> RangeModel:
         if self._model is None:
             check_alphabet(self.freqs.alphabet)
-            if self.params.PRECISION > 32:
-                raise NotImplementedError("PRECISION > 32: the gfx950 kernels keep low/range in 32 bits")
+            if self.params.PRECISION > 64:
+                raise NotImplementedError("PRECISION > 64: the gfx950 kernels keep low/range in 64 bits")
             self._model = RangeModel(self.freqs.freq_list, self.params.PRECISION, self.params.DATA_BLOCK_SIZE_BITS)
             self._index_of = self.freqs.symbol_index()
             self._alphabet = self.freqs.alphabet

@@ -1,0 +1,209 @@
+"""GPU parity, part 2: the batched C-ABI entry points (device buffers, one lane per chunk) against the CPU
+oracle on seeded inputs -- ragged and empty chunks, trailing-garbage tolerance, stream compaction (dense and
+EncodedBlockWriter framing) -- and size-independent round-trip properties at BASELINE.json configs[1] size."""
+import numpy as np
+import pytest
+
+import scl_oracle as orc
+from stanford_compression_library_amd import bench_data
+from stanford_compression_library_amd.backend import lib as backend_lib
+from stanford_compression_library_amd.backend import models
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    backend_lib.require_device()
+    return torch.device("cuda:0")
+
+
+def _stream_bits(data_np, bit_off, nbits):
+    first = int(bit_off) // 8
+    bits = np.unpackbits(data_np[first:(int(bit_off) + int(nbits) + 7) // 8 + 1])
+    lo = int(bit_off) - 8 * first
+    return bits[lo:lo + int(nbits)]
+
+
+CODERS = {
+    "rans_default": (lambda f: models.RansModel(f.tolist(), 1 << 16, 1, 32),
+                     lambda s, f: orc.rans_encode(s, f), lambda p, n, f: orc.rans_decode(p, n, f)),
+    "rans_b8": (lambda f: models.RansModel(f.tolist(), 1 << 8, 8, 32),
+                lambda s, f: orc.rans_encode(s, f, RF=1 << 8, b=8), lambda p, n, f: orc.rans_decode(p, n, f, RF=1 << 8, b=8)),
+    "rans_u64": (lambda f: models.RansModel(f.tolist(), 1 << 24, 16, 20),
+                 lambda s, f: orc.rans_encode(s, f, RF=1 << 24, b=16, size_bits=20),
+                 lambda p, n, f: orc.rans_decode(p, n, f, RF=1 << 24, b=16, size_bits=20)),
+    "tans_rf1": (lambda f: models.TansModel(f.tolist(), 1, 32),
+                 lambda s, f: orc.tans_encode(s, f, RF=1), lambda p, n, f: orc.tans_decode(p, n, f, RF=1)),
+    "tans_rf16": (lambda f: models.TansModel(f.tolist(), 16, 32),
+                  lambda s, f: orc.tans_encode(s, f, RF=16), lambda p, n, f: orc.tans_decode(p, n, f, RF=16)),
+    "range32": (lambda f: models.RangeModel(f.tolist(), 32, 32),
+                lambda s, f: orc.range_encode(s, f), lambda p, n, f: orc.range_decode(p, n, f)),
+    "range48": (lambda f: models.RangeModel(f.tolist(), 48, 17),
+                lambda s, f: orc.range_encode(s, f, precision=48, size_bits=17),
+                lambda p, n, f: orc.range_decode(p, n, f, precision=48, size_bits=17)),
+    "aec_fixed": (lambda f: models.AecModel(0, f.tolist(), f.size, 0, 1 << 30, 32, 32),
+                  lambda s, f: orc.aec_encode(s, orc.MODEL_FIXED, f.size, f_init=f),
+                  lambda p, n, f: orc.aec_decode(p, n, orc.MODEL_FIXED, f.size, f_init=f)),
+    "aec_iid": (lambda f: models.AecModel(1, [1] * f.size, f.size, 0, 1 << 30, 32, 32),
+                lambda s, f: orc.aec_encode(s, orc.MODEL_IID, f.size, f_init=np.ones(f.size)),
+                lambda p, n, f: orc.aec_decode(p, n, orc.MODEL_IID, f.size, f_init=np.ones(f.size))),
+}
+
+
+@pytest.mark.parametrize("name", list(CODERS))
+def test_batch_ragged_vs_oracle(name, dev):
+    """20 chunks of different lengths (incl. 0 and 1) in one launch; every stream equals the oracle's, every
+    decode (with 0 or 37 garbage bits after the stream) returns the symbols and the exact bit count."""
+    make_model, o_enc, o_dec = CODERS[name]
+    freq = bench_data.t256_table()
+    model = make_model(freq)
+    rng = np.random.default_rng(11)
+    lens = np.array([0, 1, 2, 3, 7, 64, 65, 100, 255, 256, 257, 300, 301, 302, 303, 304, 305, 511, 512, 333], dtype=np.int32)
+    cap = 512
+    sym = bench_data.iid_chunks_host(freq, len(lens), cap, seed=12)
+    d_sym = torch.from_numpy(sym).to(dev)
+    d_lens = torch.from_numpy(lens).to(dev)
+    enc = model.encode_batch(d_sym, lens=d_lens)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0
+    data = enc.data.cpu().numpy()
+    offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    ref = [o_enc(sym[c, :lens[c]], freq) for c in range(len(lens))]
+    for c, (rb, rn) in enumerate(ref):
+        assert int(nbits[c]) == rn, f"chunk {c}: {nbits[c]} bits vs oracle {rn}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+    # decode straight from the encoder's slots
+    skip_empty_aec = name.startswith("aec")
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    assert np.array_equal(used.cpu().numpy(), nbits)
+    dec = dec.cpu().numpy()
+    for c in range(len(lens)):
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]])
+    # decode from a dense buffer where 37 garbage bits follow every stream (streams are bit-adjacent)
+    pieces, new_off, new_avail, pos = [], [], [], 0
+    for c, (rb, rn) in enumerate(ref):
+        g = rng.integers(0, 2, 37).astype(np.uint8)
+        pieces += [np.unpackbits(rb)[:rn], g]
+        new_off.append(pos)
+        new_avail.append(rn + 37)
+        pos += rn + 37
+    packed = np.packbits(np.concatenate(pieces))
+    buf = torch.zeros(packed.size + 32, dtype=torch.uint8, device=dev)
+    buf[:packed.size] = torch.from_numpy(packed).to(dev)
+    dec2, dlens2, used2, status2 = model.decode_batch(buf, torch.tensor(new_off, dtype=torch.int64, device=dev),
+                                                      torch.tensor(new_avail, dtype=torch.int32, device=dev), cap)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    used2 = used2.cpu().numpy()
+    for c, (rb, rn) in enumerate(ref):
+        if lens[c] == 0 and skip_empty_aec:
+            continue  # quirk Q5: the reference never terminates on an empty arithmetic-coded block
+        o_sym, o_used = o_dec(np.packbits(np.concatenate([np.unpackbits(rb)[:rn], pieces[2 * c + 1]])), rn + 37, freq)
+        assert used2[c] == o_used == rn
+        assert np.array_equal(dec2[c, :lens[c]].cpu().numpy(), sym[c, :lens[c]])
+
+
+@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0)])
+def test_batch_aec_orderk_vs_oracle(K, k, dev):
+    """order-k adaptive arithmetic coding, private model per lane (BASELINE.json configs[3] shape)"""
+    n_chunks, n = 12, 700
+    sym = np.stack([bench_data.markov1_host(K, n, seed=100 + c) for c in range(n_chunks)])
+    model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, n)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in range(n_chunks):
+        rb, rn = orc.aec_encode(sym[c], orc.MODEL_ORDERK, K, k=k)
+        assert int(nbits[c]) == rn
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn])
+    assert np.array_equal(dec.cpu().numpy(), sym) and np.array_equal(used.cpu().numpy(), nbits)
+
+
+def _frame_reference(bits):
+    """EncodedBlockWriter.write_block on a bit vector (encoded_stream.py:23-46,94-103,150-175), in numpy"""
+    n = bits.size
+    pad = (8 - (n + 3) % 8) % 8
+    payload = np.concatenate([np.unpackbits(np.array([pad], np.uint8))[5:], np.zeros(pad, np.uint8), bits])
+    assert payload.size % 8 == 0
+    nbytes = payload.size // 8
+    return np.concatenate([np.frombuffer(int(nbytes).to_bytes(4, "big"), np.uint8), np.packbits(payload)])
+
+
+@pytest.mark.parametrize("name", ["rans_default", "range32", "aec_iid"])
+@pytest.mark.parametrize("framed", [False, True])
+def test_compact_dense_and_framed(name, framed, dev):
+    make_model, o_enc, _ = CODERS[name]
+    freq = bench_data.t256_table()
+    model = make_model(freq)
+    lens = np.array([0, 1, 5, 13, 100, 101, 102, 103, 104, 105, 106, 107, 200, 17, 1, 0, 64], dtype=np.int32)
+    sym = bench_data.iid_chunks_host(freq, len(lens), 200, seed=21)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dense, offsets = models.compact(enc, framed=framed)
+    dense, offsets = dense.cpu().numpy(), offsets.cpu().numpy()
+    expect = []
+    for c in range(len(lens)):
+        rb, rn = o_enc(sym[c, :lens[c]], freq)
+        bits = np.unpackbits(rb)[:rn]
+        expect.append(_frame_reference(bits) if framed else np.packbits(bits))
+    sizes = np.array([e.size for e in expect])
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(sizes)]))
+    for c, e in enumerate(expect):
+        assert np.array_equal(dense[offsets[c]:offsets[c + 1]], e), f"record {c}"
+
+
+def test_status_reporting(dev):
+    freq = bench_data.t256_table()[:16].copy()
+    freq[0] += 4096 - freq.sum()
+    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+    sym = np.full((3, 64), int(np.argmin(freq)), dtype=np.uint8)  # rare symbol: many bits per symbol
+    sym[1, 10] = 200  # symbol outside the 16-entry alphabet -> KeyError in the reference
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), out_stride=16)  # far too small a slot
+    torch.cuda.synchronize()
+    st = enc.status.cpu().numpy()
+    assert st[1] & backend_lib.ST_SYMBOL and all(s & backend_lib.ST_CAPACITY for s in st)
+    # a corrupted stream must flag the final-state assert (rANS.py:295) or truncation, never crash
+    enc = model.encode_batch(torch.from_numpy(sym[:1] * 0 + 3).to(dev))
+    torch.cuda.synchronize()
+    byte = int(enc.bit_offset[0].item()) // 8 + 9
+    enc.data[byte] ^= 0x5A
+    _, _, _, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, 64)
+    torch.cuda.synchronize()
+    assert int(status[0]) & (backend_lib.ST_STATE | backend_lib.ST_TRUNCATED)
+
+
+@pytest.mark.parametrize("table", ["t256", "uniform"])
+def test_config2_roundtrip_properties(table, dev):
+    """BASELINE.json configs[1]: 64 Ki chunks x 4 KiB.  Size-independent properties: decode(encode(x)) == x for
+    every chunk, consumed == produced bits, and byte-equality with the oracle on a fixed sample of chunks."""
+    freq = bench_data.t256_table() if table == "t256" else bench_data.uniform256_table()
+    n_chunks, chunk_len = 65536, 4096
+    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=2, device=dev)
+    enc = model.encode_batch(sym)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    assert torch.equal(dec, sym) and torch.equal(used, enc.nbits)
+    assert int(dlens.min()) == chunk_len == int(dlens.max())
+    sample = [0, 1, 4095, 32768, n_chunks - 1]
+    offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in sample:
+        rb, rn = orc.rans_encode(sym[c].cpu().numpy(), freq)
+        assert int(nbits[c]) == rn
+        lo = int(offs[c]) // 8
+        window = enc.data[lo:lo + (rn + 7) // 8 + 2].cpu().numpy()
+        bits = np.unpackbits(window)[int(offs[c]) % 8:][:rn]
+        assert np.array_equal(bits, np.unpackbits(rb)[:rn])
+    # the encoded size is what the model predicts: bits/symbol within 1 % of the cross-entropy + header
+    p = freq / freq.sum()
+    h = float(-(p * np.log2(p)).sum())
+    got = float(enc.nbits.double().mean().item() - 61) / chunk_len
+    assert abs(got - h) < 0.05, (got, h)
