@@ -18,29 +18,7 @@
 
 #include "scl_common.h"
 
-struct RansDev {
-    u32 K;
-    u32 b;
-    u32 size_bits;
-    u32 nsb;
-    u64 M, RF, L;
-    u32 m_log2;  // log2(M) if M is a power of two, else 0xFFFFFFFF
-    const u32 *d_freq;
-    const u32 *d_cum;
-};
-
-struct scl_rans_model {
-    RansDev dev;
-    u64 H;
-    u32 max_bits_per_symbol;
-    u32 state32;  // H < 2^32
-    u32 fast;
-    u32 *d_freq;
-    u32 *d_cum;
-    // fast-path tables
-    uint4 *d_enc_tab;  // [K]  {f | k0<<16.., thresh, rcp, cum/cmpl}
-    u32 *d_dec_tab;    // [M]  slot -> packed {sym, f-1, slot-cum}
-};
+#include "scl_rans_internal.h"
 
 // =====================================================================================================
 // generic kernels
@@ -220,6 +198,11 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
     }
     m->dev.d_freq = m->d_freq;
     m->dev.d_cum = m->d_cum;
+    const int rc = rans_fast_build_tables(m, h_freq, cum);
+    if (rc != SCL_OK) {
+        scl_rans_model_destroy(m);
+        return rc;
+    }
     *out = m;
     return SCL_OK;
 }
@@ -278,7 +261,12 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
     hipStream_t st = (hipStream_t)stream;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->state32)
+    // fast path: qualifying model, 16-byte aligned rows, and slots that cannot overflow (it has no capacity check)
+    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+        out_stride >= scl_rans_slot_bytes(m, chunk_len))
+        rans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                d_out_bit_offset, d_out_nbits, d_status, st);
+    else if (m->state32)
         hipLaunchKernelGGL(rans_encode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
     else
@@ -299,7 +287,10 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
     hipStream_t st = (hipStream_t)stream;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->state32)
+    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+        rans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                out_cap, d_out_lens, d_consumed, d_status, st);
+    else if (m->state32)
         hipLaunchKernelGGL(rans_decode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
                            d_status);

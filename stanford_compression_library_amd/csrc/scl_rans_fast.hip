@@ -1,0 +1,391 @@
+// scl_rans_fast.hip -- the gfx950 fast path of batched rANS (BASELINE.json configs[1] / headline):
+// u32 state, M = 2^m (m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r, H < 2^31.
+// Same bit stream as the generic kernels in scl_rans.hip (and as reference rANS.py:186-210 / :270-297);
+// what changes is how a lane spends its instructions:
+//
+//  encode, per symbol (one 16-byte LDS table read):
+//    k     = k0[s] + (x >= thresh[s])                    closed form of shrink_state's while-loop
+//                                                         (rANS.py:149-161; tANS.py:74-86 gives the same rule)
+//    field = low k bits of x;  xs = x >> k
+//    q     = floor(xs / f) = mulhi(x << (32-nsb), rcp[s]) >> (s[s] + k),  s[s] + k0[s] == m
+//            with rcp = ceil(2^(nsb+s) / f), s = ceil(log2 f): exact for every x < 2^nsb
+//            (error term x*e/(f*2^(nsb+s+k)) < 2^-(s+k) <= 1/(f*2^k))
+//    x     = xs + c[s] + q*(M - f[s])                     == (xs//f)*M + c + xs%f  (rANS.py:138-147)
+//    Two fields are merged before they touch the 32-bit accumulator; completed big-endian words go
+//    through a 4-register queue and leave as one aligned 16-byte store per lane, back to front.
+//  decode, per symbol (one 4-byte LDS table read, slot -> {sym, f, slot - c}):
+//    x  = (x >> m)*f + (slot - c)                          rans_base_decode_step (rANS.py:234-249)
+//    nb = clz(x) - (32 - nsb);  x = (x << nb) | next nb bits   closed form of expand_state (:251-260),
+//         done as one v_alignbit on a normalised copy.
+//    The lane reads its stream through 16-byte loads into a 4-register queue (one block prefetched) and
+//    writes symbols back to front, 16 per store.
+//
+// Input symbols are read 16 bytes per lane per load with the next block prefetched.  Per-lane accesses
+// are 16-byte granules at a 4 KiB lane stride; DESIGN.md discusses what that costs at L2 and the
+// wave-cooperative alternative.
+#include <vector>
+
+#include "scl_rans_internal.h"
+
+#define RF_THREADS 256
+
+__device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
+
+// ---------------------------------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------------------------------
+struct EncOut {
+    u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
+    u32 nacc;  // number of pending bits
+    u32 w0, w1, w2, w3;  // completed big-endian words, w0 newest (lowest address)
+    u32 cnt;             // how many of them are valid
+    u8 *wp;              // everything at and after wp is already in memory
+
+    __device__ __forceinline__ void init(u8 *slot_end) {
+        lo = 0;
+        nacc = 0;
+        w0 = w1 = w2 = w3 = 0;
+        cnt = 0;
+        wp = slot_end;
+    }
+    // append `w` bits (v < 2^w, w <= 32) in front of the stream
+    __device__ __forceinline__ void put(u32 v, u32 w) {
+        const u64 t = (u64)v << nacc;
+        lo |= (u32)t;
+        nacc += w;
+        if (nacc >= 32) {
+            w3 = w2;
+            w2 = w1;
+            w1 = w0;
+            w0 = __builtin_bswap32(lo);
+            lo = (u32)(t >> 32);
+            nacc -= 32;
+            if (++cnt == 4) {
+                wp -= 16;
+                *reinterpret_cast<uint4 *>(wp) = make_uint4(w0, w1, w2, w3);
+                cnt = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ u64 finish(const u8 *slot_end) {
+        u32 *p = reinterpret_cast<u32 *>(wp);
+        if (cnt == 3) {
+            p[-1] = w2;
+            p[-2] = w1;
+            p[-3] = w0;
+        } else if (cnt == 2) {
+            p[-1] = w1;
+            p[-2] = w0;
+        } else if (cnt == 1) {
+            p[-1] = w0;
+        }
+        p -= cnt;
+        if (nacc) p[-1] = __builtin_bswap32(lo);  // zero bits in front of the stream
+        return (u64)(slot_end - reinterpret_cast<const u8 *>(p)) * 8 + nacc;
+    }
+};
+
+struct EncSym {
+    u32 bits, k;
+};
+
+// s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f, s = ceil(log2 f)), so the quotient
+// shift s + k is just m + (x >= thresh).
+__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 s, const uint4 *s_tab, u32 xshift, u32 m_log2) {
+    const uint4 e = s_tab[s];
+    const u32 ge = (x >= e.y) ? 1u : 0u;
+    const u32 k = e.w + ge;
+    const u32 q = rf_umulhi(x << xshift, e.x) >> (m_log2 + ge);
+    EncSym r;
+    r.bits = __builtin_amdgcn_ubfe(x, 0, k);
+    r.k = k;
+    x = (x >> k) + (e.z & 0xFFFFu) + __umul24(q, e.z >> 16);
+    return r;
+}
+
+template <bool CHECK_SYM>
+__global__ void __launch_bounds__(RF_THREADS) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+                                                                     u64 sym_stride, const u32 *__restrict__ lens,
+                                                                     u32 chunk_len, u64 n_chunks,
+                                                                     u8 *__restrict__ out, u64 out_stride,
+                                                                     u64 *__restrict__ out_bit_off,
+                                                                     u32 *__restrict__ out_nbits,
+                                                                     u32 *__restrict__ status) {
+    __shared__ uint4 s_tab[256];
+    s_tab[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 n = lens ? lens[c] : chunk_len;
+    const u8 *src = sym + c * sym_stride;
+    u8 *slot_end = out + (c + 1) * out_stride;
+    const u32 xshift = 32 - P.nsb;
+    EncOut o;
+    o.init(slot_end);
+    u32 x = P.L;
+    u32 bad = 0;
+
+    const u32 n16 = n >> 4;
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (n16) cur = src16[0];
+    for (u32 t = 0; t < n16; ++t) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (t + 1 < n16) nxt = src16[t + 1];  // prefetch: one 16-byte block ahead
+        const u32 wv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 sa = (wv[d] >> (16 * h)) & 0xFFu;
+                const u32 sb = (wv[d] >> (16 * h + 8)) & 0xFFu;
+                if (CHECK_SYM) bad |= (sa >= P.K) | (sb >= P.K);
+                const EncSym a = rf_encode_symbol(x, sa, s_tab, xshift, P.m_log2);
+                const EncSym b = rf_encode_symbol(x, sb, s_tab, xshift, P.m_log2);
+                // the later symbol's field goes in front (more significant side) of the earlier one's
+                o.put(a.bits | (b.bits << a.k), a.k + b.k);
+            }
+        }
+        cur = nxt;
+    }
+    for (u32 i = n16 << 4; i < n; ++i) {  // ragged tail
+        const u32 s = src[i];
+        if (CHECK_SYM) bad |= (s >= P.K);
+        const EncSym a = rf_encode_symbol(x, s, s_tab, xshift, P.m_log2);
+        o.put(a.bits, a.k);
+    }
+    o.put(x, P.nsb);
+    u32 st = bad ? SCL_ST_SYMBOL : 0u;
+    if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
+    o.put(n, P.size_bits);
+    const u64 total = o.finish(slot_end);
+    out_bit_off[c] = (c + 1) * out_stride * 8 - total;
+    out_nbits[c] = (u32)total;
+    if (status) status[c] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------------
+struct DecIn {
+    const uint4 *base;
+    u64 n_blocks;  // readable 16-byte blocks
+    u64 blk;       // index of the block currently in q
+    uint4 q, nx;   // current block (remaining words shifted to the front), prefetched next block
+    u32 qc;        // words left in q
+    u32 A, B;      // 64-bit window, big-endian words
+    int sh;        // window = low32((A:B) >> sh); sh in [0,31]
+    u64 consumed;  // bits consumed so far
+
+    __device__ __forceinline__ uint4 load_block(u64 i) const {
+        return (i < n_blocks) ? base[i] : make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ u32 next_word() {
+        const u32 v = __builtin_bswap32(q.x);
+        q.x = q.y;
+        q.y = q.z;
+        q.z = q.w;
+        if (--qc == 0) {
+            q = nx;
+            qc = 4;
+            ++blk;
+            nx = load_block(blk + 1);
+        }
+        return v;
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off) {
+        base = reinterpret_cast<const uint4 *>(in);
+        n_blocks = in_size_bytes >> 4;
+        blk = bit_off >> 7;
+        q = load_block(blk);
+        nx = load_block(blk + 1);
+        qc = 4;
+        for (u32 skip = (u32)(bit_off >> 5) & 3u; skip; --skip) (void)next_word();
+        const u32 pos = (u32)bit_off & 31u;
+        const u32 first = next_word();
+        if (pos == 0) {
+            A = 0;
+            B = first;
+            sh = 0;
+        } else {
+            A = first;
+            B = next_word();
+            sh = 32 - (int)pos;
+        }
+        consumed = 0;
+    }
+    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
+    __device__ __forceinline__ void advance(u32 nb) {  // nb <= 32
+        sh -= (int)nb;
+        consumed += nb;
+        if (sh < 0) {
+            A = B;
+            B = next_word();
+            sh += 32;
+        }
+    }
+    __device__ __forceinline__ u32 get(u32 w) {  // 1 <= w <= 32
+        const u32 v = look() >> (32 - w);
+        advance(w);
+        return v;
+    }
+};
+
+// decode one symbol: state update + renormalisation from the 32-bit lookahead `lk` (bits are consumed
+// from its top); returns the packed table entry (symbol in the low byte) and the number of bits used
+__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, const u32 *s_dtab, u32 m_log2,
+                                                u32 slot_mask, u32 clz_bias) {
+    const u32 e = s_dtab[x & slot_mask];
+    x = __umul24(x >> m_log2, (e >> 8) & 0xFFFu) + (e >> 20);
+    const u32 cl = (u32)__builtin_clz(x);                            // x >= 2^r > 0
+    const u32 y = __builtin_amdgcn_alignbit(x, lk, 32 - cl);         // (x << cl) | (lk >> (32 - cl)), cl in [1,31]
+    x = y >> clz_bias;                                                // keep nb = cl - clz_bias new bits
+    const u32 nb = cl - clz_bias;
+    lk <<= nb;
+    used = nb;
+    return e;
+}
+
+__global__ void __launch_bounds__(RF_THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
+                                                                     u64 in_size_bytes,
+                                                                     const u64 *__restrict__ bit_off,
+                                                                     const u32 *__restrict__ in_nbits, u64 n_chunks,
+                                                                     u8 *__restrict__ out_sym, u64 out_stride,
+                                                                     u32 out_cap, u32 *__restrict__ out_lens,
+                                                                     u32 *__restrict__ consumed,
+                                                                     u32 *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) u32 s_dtab[];
+    const u32 M = 1u << P.m_log2;
+    for (u32 i = threadIdx.x; i < M; i += RF_THREADS) s_dtab[i] = P.d_dec_tab[i];
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 avail = in_nbits[c];
+    u32 st = 0;
+    if (avail < P.size_bits + P.nsb) {  // header does not fit
+        out_lens[c] = 0;
+        consumed[c] = P.size_bits + P.nsb;
+        if (status) status[c] = SCL_ST_TRUNCATED;
+        return;
+    }
+    DecIn r;
+    r.init(in, in_size_bytes, bit_off[c]);
+    u32 n = r.get(P.size_bits);
+    u32 x = r.get(P.nsb);
+    out_lens[c] = n;
+    if (n > out_cap) {
+        st |= SCL_ST_CAPACITY;
+        n = 0;
+    }
+    const u32 st_header = st;
+    const u32 slot_mask = M - 1, clz_bias = 32 - P.nsb;
+    u8 *dst = out_sym + c * out_stride;
+
+    // symbols come out last-first (rANS.py:291): first the ragged head of the last 16-byte block ...
+    u32 i = n;
+    while (i & 15u) {
+        u32 lk = r.look(), used;
+        const u32 e = rf_decode_symbol(x, lk, used, s_dtab, P.m_log2, slot_mask, clz_bias);
+        r.advance(used);
+        dst[--i] = (u8)e;
+    }
+    // ... then whole blocks of 16, assembled in registers and stored with one 16-byte store
+    while (i) {
+        u32 ow[4];
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {
+            u32 o = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32 lk = r.look(), ua, ub;
+                const u32 ea = rf_decode_symbol(x, lk, ua, s_dtab, P.m_log2, slot_mask, clz_bias);
+                const u32 eb = rf_decode_symbol(x, lk, ub, s_dtab, P.m_log2, slot_mask, clz_bias);
+                r.advance(ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
+                o = __builtin_amdgcn_perm(o, ea, 0x06050400u);  // o = (o << 8) | (ea & 0xFF)
+                o = __builtin_amdgcn_perm(o, eb, 0x06050400u);
+            }
+            ow[d] = o;
+        }
+        i -= 16;
+        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+    if (r.consumed > avail) st |= SCL_ST_TRUNCATED;
+    else if (st_header == 0 && x != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
+    consumed[c] = (u32)r.consumed;
+    if (status) status[c] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static u32 ceil_log2_u32(u32 v) {
+    u32 s = 0;
+    while ((1ull << s) < v) ++s;
+    return s;
+}
+
+// Decides whether the model qualifies and uploads the two tables.  Returns SCL_OK also when the model
+// simply does not qualify (m->fast stays 0).
+int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum) {
+    const RansDev &D = m->dev;
+    m->fast = 0;
+    if (D.b != 1 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || D.m_log2 < 1) return SCL_OK;
+    if ((D.RF & (D.RF - 1)) != 0 || D.RF > (1u << 23) || D.nsb > 30 || D.K < 2) return SCL_OK;
+    if (m->max_bits_per_symbol > 12) return SCL_OK;
+    const u32 M = (u32)D.M, nsb = D.nsb;
+    std::vector<uint4> enc(256);
+    std::vector<u32> dec(M);
+    for (u32 s = 0; s < 256; ++s) {
+        const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
+        const u32 f = h_freq[src], c = h_cum[src];
+        const u64 two_rf_f = 2ull * D.RF * f;                           // max_shrunk_state + 1 (rANS.py:112)
+        const u32 k0 = nsb - scl_bit_width_u64(two_rf_f - 1);           // tANS.py:80-81
+        const u64 thresh = two_rf_f << k0;                              // tANS.py:84 (<= 2^nsb)
+        const u32 sh = ceil_log2_u32(f);
+        const u64 rcp = ((1ull << (nsb + sh)) + f - 1) / f;             // ceil(2^(nsb+sh)/f) <= 2^(nsb+1)+1
+        if (rcp >> 32) return SCL_OK;
+        if (sh + k0 != D.m_log2) return SCL_OK;  // cannot happen (see rf_encode_symbol)
+        enc[s] = make_uint4((u32)rcp, (u32)thresh, c | ((M - f) << 16), k0);
+    }
+    for (u32 s = 0; s < D.K; ++s)
+        for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = s | (h_freq[s] << 8) | (j << 20);
+    hipError_t e = hipMalloc((void **)&m->d_enc_tab, 256 * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_dec_tab, M * sizeof(u32));
+    if (e == hipSuccess) e = hipMemcpy(m->d_enc_tab, enc.data(), 256 * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_dec_tab, dec.data(), M * sizeof(u32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        scl_set_error("rans_model_create: fast-path table upload failed: %s", hipGetErrorString(e));
+        return SCL_E_HIP;
+    }
+    m->fdev.K = D.K;
+    m->fdev.nsb = nsb;
+    m->fdev.size_bits = D.size_bits;
+    m->fdev.m_log2 = D.m_log2;
+    m->fdev.L = (u32)D.L;
+    m->fdev.d_enc_tab = m->d_enc_tab;
+    m->fdev.d_dec_tab = m->d_dec_tab;
+    m->fast = 1;
+    return SCL_OK;
+}
+
+void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                             u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                             u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
+    if (m->fdev.K < 256)
+        hipLaunchKernelGGL(rans_encode_fast_kernel<true>, dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+    else
+        hipLaunchKernelGGL(rans_encode_fast_kernel<false>, dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+}
+
+void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
+                             const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
+    const u32 lds = (1u << m->fdev.m_log2) * sizeof(u32);
+    hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(blocks), dim3(RF_THREADS), lds, st, m->fdev, d_in,
+                       in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                       d_consumed, d_status);
+}

@@ -1,0 +1,48 @@
+// scl_rans_internal.h -- model layout shared by scl_rans.hip (generic kernels, host API) and
+// scl_rans_fast.hip (the gfx950 fast path).  Internal to csrc/.
+#pragma once
+#include "scl_common.h"
+
+struct RansDev {
+    u32 K;
+    u32 b;
+    u32 size_bits;
+    u32 nsb;
+    u64 M, RF, L;
+    u32 m_log2;  // log2(M) if M is a power of two, else 0xFFFFFFFF
+    const u32 *d_freq;
+    const u32 *d_cum;
+};
+
+// fast path: H < 2^31, M = 2^m (m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r
+struct RansFastDev {
+    u32 K;
+    u32 nsb;        // NUM_STATE_BITS = r + m + 1 <= 30
+    u32 size_bits;
+    u32 m_log2;
+    u32 L;
+    const uint4 *d_enc_tab;  // [256] {rcp, thresh, cum | (M-f) << 16, k0}
+    const u32 *d_dec_tab;    // [M]   slot -> sym | f << 8 | (slot - cum) << 20
+};
+
+struct scl_rans_model {
+    RansDev dev;
+    RansFastDev fdev;
+    u64 H;
+    u32 max_bits_per_symbol;
+    u32 state32;  // H < 2^32
+    u32 fast;
+    u32 *d_freq;
+    u32 *d_cum;
+    uint4 *d_enc_tab;
+    u32 *d_dec_tab;
+};
+
+// scl_rans_fast.hip
+int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum);
+void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                             u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                             u32 *d_status, hipStream_t st);
+void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
+                             const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);
