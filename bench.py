@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--coder", choices=["rans", "tans", "range"], default="rans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
+    ap.add_argument("--sym-pad", type=int, default=0, help="experiment: extra bytes between input rows")
     return ap.parse_args()
 
 
@@ -133,6 +134,10 @@ def main():
     model, coder_params = make_model(args, freq)
     n_chunks, chunk_len = args.chunks, args.chunk_len
     sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
+    if args.sym_pad:
+        padded = torch.zeros((n_chunks, chunk_len + args.sym_pad), dtype=torch.uint8, device=dev)
+        padded[:, :chunk_len] = sym
+        sym = padded[:, :chunk_len]
     enc = model.alloc_encoded(n_chunks, chunk_len, dev)
     dec_out = model.alloc_decoded(n_chunks, chunk_len, dev)
 

@@ -34,19 +34,32 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 // ---------------------------------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------------------------------
+// Memory granularity (profiles/r01_v2_pmc_summary.txt): with one lane per 4 KiB chunk a CU owns 1024
+// open cache lines for input and 1024 for output -- more than L1 and, per XCD, the whole L2.  16-byte
+// lane accesses therefore each became their own fabric request (61 M read + 61 M write requests per
+// GiB, 3.6x / 2.3x traffic amplification).  So every lane now moves whole lines:
+//   input : 128 bytes (one line) per lane as 8 back-to-back 16-byte loads into registers, next line
+//           prefetched while the current one is encoded (ping-pong register buffers);
+//   output: completed big-endian words go to a per-lane ring in LDS (word w of thread t at [w][t]: bank =
+//           t mod 32 for every w, so the scattered ds_write_b32 never conflict), and leave as 64
+//           contiguous bytes (4 back-to-back 16-byte stores) once 16 words are pending.
+#define RF_RING_WORDS 32
+
 struct EncOut {
     u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
     u32 nacc;  // number of pending bits
-    u32 w0, w1, w2, w3;  // completed big-endian words, w0 newest (lowest address)
-    u32 cnt;             // how many of them are valid
-    u8 *wp;              // everything at and after wp is already in memory
+    u32 wr;    // words completed so far (word j of the stream counted from its END)
+    u32 fl;    // words already stored to memory (multiple of 16 until finish)
+    u32 *ring;  // this thread's column of the LDS ring
+    u8 *slot_end;
 
-    __device__ __forceinline__ void init(u8 *slot_end) {
+    __device__ __forceinline__ void init(u32 *ring_, u8 *slot_end_) {
         lo = 0;
         nacc = 0;
-        w0 = w1 = w2 = w3 = 0;
-        cnt = 0;
-        wp = slot_end;
+        wr = 0;
+        fl = 0;
+        ring = ring_;
+        slot_end = slot_end_;
     }
     // append `w` bits (v < 2^w, w <= 32) in front of the stream
     __device__ __forceinline__ void put(u32 v, u32 w) {
@@ -54,34 +67,33 @@ struct EncOut {
         lo |= (u32)t;
         nacc += w;
         if (nacc >= 32) {
-            w3 = w2;
-            w2 = w1;
-            w1 = w0;
-            w0 = __builtin_bswap32(lo);
+            ring[(wr & (RF_RING_WORDS - 1)) * RF_THREADS] = __builtin_bswap32(lo);
+            ++wr;
             lo = (u32)(t >> 32);
             nacc -= 32;
-            if (++cnt == 4) {
-                wp -= 16;
-                *reinterpret_cast<uint4 *>(wp) = make_uint4(w0, w1, w2, w3);
-                cnt = 0;
-            }
         }
     }
-    __device__ __forceinline__ u64 finish(const u8 *slot_end) {
-        u32 *p = reinterpret_cast<u32 *>(wp);
-        if (cnt == 3) {
-            p[-1] = w2;
-            p[-2] = w1;
-            p[-3] = w0;
-        } else if (cnt == 2) {
-            p[-1] = w1;
-            p[-2] = w0;
-        } else if (cnt == 1) {
-            p[-1] = w0;
+    // 16 pending words -> 64 contiguous bytes; call at least every 16 symbols (<= 6 new words)
+    __device__ __forceinline__ void maybe_flush() {
+        if (wr - fl >= 16) {
+            const u32 *r = ring + (fl & 16) * RF_THREADS;
+            u32 w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = r[j * RF_THREADS];
+            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(fl + 16));
+            p[0] = make_uint4(w[15], w[14], w[13], w[12]);
+            p[1] = make_uint4(w[11], w[10], w[9], w[8]);
+            p[2] = make_uint4(w[7], w[6], w[5], w[4]);
+            p[3] = make_uint4(w[3], w[2], w[1], w[0]);
+            fl += 16;
         }
-        p -= cnt;
-        if (nacc) p[-1] = __builtin_bswap32(lo);  // zero bits in front of the stream
-        return (u64)(slot_end - reinterpret_cast<const u8 *>(p)) * 8 + nacc;
+    }
+    __device__ __forceinline__ u64 finish() {
+        maybe_flush();
+        u32 *end32 = reinterpret_cast<u32 *>(slot_end);
+        for (u32 j = fl; j < wr; ++j) end32[-(i64)j - 1] = ring[(j & (RF_RING_WORDS - 1)) * RF_THREADS];
+        if (nacc) end32[-(i64)wr - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
+        return (u64)wr * 32 + nacc;
     }
 };
 
@@ -103,8 +115,37 @@ __device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 s, const uint4 *s
     return r;
 }
 
+// 16 symbols (one 16-byte register) -> 8 merged field pairs
 template <bool CHECK_SYM>
-__global__ void __launch_bounds__(RF_THREADS) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, const uint4 *s_tab,
+                                            u32 xshift, u32 m_log2, u32 K) {
+    const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 sa = (wv[d] >> (16 * h)) & 0xFFu;
+            const u32 sb = (wv[d] >> (16 * h + 8)) & 0xFFu;
+            if (CHECK_SYM) bad = max(bad, max(sa, sb));  // largest symbol index seen; compared with K once
+            const EncSym a = rf_encode_symbol(x, sa, s_tab, xshift, m_log2);
+            const EncSym b = rf_encode_symbol(x, sb, s_tab, xshift, m_log2);
+            // the later symbol's field goes in front (more significant side) of the earlier one's
+            o.put(a.bits | (b.bits << a.k), a.k + b.k);
+        }
+    }
+    o.maybe_flush();
+}
+
+struct Line128 {
+    uint4 v[8];
+    __device__ __forceinline__ void load(const uint4 *p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+};
+
+template <bool CHECK_SYM>
+__global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                      u64 sym_stride, const u32 *__restrict__ lens,
                                                                      u32 chunk_len, u64 n_chunks,
                                                                      u8 *__restrict__ out, u64 out_stride,
@@ -112,53 +153,49 @@ __global__ void __launch_bounds__(RF_THREADS) rans_encode_fast_kernel(RansFastDe
                                                                      u32 *__restrict__ out_nbits,
                                                                      u32 *__restrict__ status) {
     __shared__ uint4 s_tab[256];
+    __shared__ u32 s_ring[RF_RING_WORDS * RF_THREADS];
     s_tab[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    u8 *slot_end = out + (c + 1) * out_stride;
-    const u32 xshift = 32 - P.nsb;
+    const u32 xshift = 32 - P.nsb, m_log2 = P.m_log2, K = P.K;
     EncOut o;
-    o.init(slot_end);
+    o.init(s_ring + threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L;
     u32 bad = 0;
 
-    const u32 n16 = n >> 4;
+    const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (n16) cur = src16[0];
-    for (u32 t = 0; t < n16; ++t) {
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (t + 1 < n16) nxt = src16[t + 1];  // prefetch: one 16-byte block ahead
-        const u32 wv[4] = {cur.x, cur.y, cur.z, cur.w};
+    Line128 bufA, bufB;
+    if (n_lines) bufA.load(src16);
+    for (u32 t = 0; t < n_lines; t += 2) {
+        if (t + 1 < n_lines) bufB.load(src16 + 8 * (t + 1));  // prefetch the next line
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int i = 0; i < 8; ++i) rf_encode16<CHECK_SYM>(bufA.v[i], x, o, bad, s_tab, xshift, m_log2, K);
+        if (t + 1 < n_lines) {
+            if (t + 2 < n_lines) bufA.load(src16 + 8 * (t + 2));
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32 sa = (wv[d] >> (16 * h)) & 0xFFu;
-                const u32 sb = (wv[d] >> (16 * h + 8)) & 0xFFu;
-                if (CHECK_SYM) bad |= (sa >= P.K) | (sb >= P.K);
-                const EncSym a = rf_encode_symbol(x, sa, s_tab, xshift, P.m_log2);
-                const EncSym b = rf_encode_symbol(x, sb, s_tab, xshift, P.m_log2);
-                // the later symbol's field goes in front (more significant side) of the earlier one's
-                o.put(a.bits | (b.bits << a.k), a.k + b.k);
-            }
+            for (int i = 0; i < 8; ++i) rf_encode16<CHECK_SYM>(bufB.v[i], x, o, bad, s_tab, xshift, m_log2, K);
         }
-        cur = nxt;
     }
-    for (u32 i = n16 << 4; i < n; ++i) {  // ragged tail
+    u32 i = n_lines << 7;
+    for (; i + 16 <= n; i += 16)  // ragged tail: whole 16-byte blocks, then single symbols
+        rf_encode16<CHECK_SYM>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, s_tab, xshift, m_log2, K);
+    for (; i < n; ++i) {
         const u32 s = src[i];
-        if (CHECK_SYM) bad |= (s >= P.K);
-        const EncSym a = rf_encode_symbol(x, s, s_tab, xshift, P.m_log2);
+        if (CHECK_SYM) bad = max(bad, s);
+        const EncSym a = rf_encode_symbol(x, s, s_tab, xshift, m_log2);
         o.put(a.bits, a.k);
+        if ((i & 15u) == 15u) o.maybe_flush();
     }
+    o.maybe_flush();
     o.put(x, P.nsb);
-    u32 st = bad ? SCL_ST_SYMBOL : 0u;
+    u32 st = (CHECK_SYM && bad >= K) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
     o.put(n, P.size_bits);
-    const u64 total = o.finish(slot_end);
+    const u64 total = o.finish();
     out_bit_off[c] = (c + 1) * out_stride * 8 - total;
     out_nbits[c] = (u32)total;
     if (status) status[c] = st;
@@ -167,40 +204,68 @@ __global__ void __launch_bounds__(RF_THREADS) rans_encode_fast_kernel(RansFastDe
 // ---------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------
+// Same line-granular rule as the encoder:
+//   input : the lane's stream arrives in 64-byte blocks (4 back-to-back 16-byte loads, one block prefetched
+//           in registers), is byte-swapped once and parked in a per-lane LDS ring of 32 words ([w][t] layout,
+//           conflict-free); the bit window refills one word at a time from the ring;
+//   output: 128 decoded symbols are assembled in 8 registers and leave as one full line
+//           (8 back-to-back 16-byte stores), last line of the chunk first.
+#define RD_THREADS 1024  // one workgroup per CU: 16 KiB slot table + 128 KiB ring
+
 struct DecIn {
     const uint4 *base;
-    u64 n_blocks;  // readable 16-byte blocks
-    u64 blk;       // index of the block currently in q
-    uint4 q, nx;   // current block (remaining words shifted to the front), prefetched next block
-    u32 qc;        // words left in q
-    u32 A, B;      // 64-bit window, big-endian words
-    int sh;        // window = low32((A:B) >> sh); sh in [0,31]
-    u64 consumed;  // bits consumed so far
+    u64 n_blocks16;  // readable 16-byte blocks
+    u64 next64;      // index of the next 64-byte block to prefetch
+    uint4 pf[4];     // prefetched block, next to enter the ring
+    u32 rd, wrw;     // words consumed from / written to the ring
+    u32 *ring;       // this thread's column
+    u32 A, B;        // 64-bit window, big-endian words
+    int sh;          // lookahead = low32((A:B) >> sh); sh in [0,31]
+    u32 consumed;    // bits consumed so far
 
-    __device__ __forceinline__ uint4 load_block(u64 i) const {
-        return (i < n_blocks) ? base[i] : make_uint4(0, 0, 0, 0);
+    __device__ __forceinline__ void load64(u64 j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u64 idx = j * 4 + i;
+            pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void push_pf() {
+        u32 *r = ring + (wrw & 16) * RD_THREADS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[(4 * i + 0) * RD_THREADS] = __builtin_bswap32(pf[i].x);
+            r[(4 * i + 1) * RD_THREADS] = __builtin_bswap32(pf[i].y);
+            r[(4 * i + 2) * RD_THREADS] = __builtin_bswap32(pf[i].z);
+            r[(4 * i + 3) * RD_THREADS] = __builtin_bswap32(pf[i].w);
+        }
+        wrw += 16;
     }
     __device__ __forceinline__ u32 next_word() {
-        const u32 v = __builtin_bswap32(q.x);
-        q.x = q.y;
-        q.y = q.z;
-        q.z = q.w;
-        if (--qc == 0) {
-            q = nx;
-            qc = 4;
-            ++blk;
-            nx = load_block(blk + 1);
-        }
+        const u32 v = ring[(rd & 31u) * RD_THREADS];
+        ++rd;
         return v;
     }
-    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off) {
+    // call at least every 16 symbols (<= 6 words consumed in between)
+    __device__ __forceinline__ void maybe_refill() {
+        if (wrw - rd <= 16) {
+            push_pf();
+            load64(next64++);
+        }
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 *ring_) {
         base = reinterpret_cast<const uint4 *>(in);
-        n_blocks = in_size_bytes >> 4;
-        blk = bit_off >> 7;
-        q = load_block(blk);
-        nx = load_block(blk + 1);
-        qc = 4;
-        for (u32 skip = (u32)(bit_off >> 5) & 3u; skip; --skip) (void)next_word();
+        n_blocks16 = in_size_bytes >> 4;
+        ring = ring_;
+        const u64 j0 = bit_off >> 9;
+        wrw = 0;
+        load64(j0);
+        push_pf();
+        load64(j0 + 1);
+        push_pf();
+        load64(j0 + 2);
+        next64 = j0 + 3;
+        rd = (u32)(bit_off >> 5) & 15u;
         const u32 pos = (u32)bit_off & 31u;
         const u32 first = next_word();
         if (pos == 0) {
@@ -237,16 +302,38 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, cons
                                                 u32 slot_mask, u32 clz_bias) {
     const u32 e = s_dtab[x & slot_mask];
     x = __umul24(x >> m_log2, (e >> 8) & 0xFFFu) + (e >> 20);
-    const u32 cl = (u32)__builtin_clz(x);                            // x >= 2^r > 0
-    const u32 y = __builtin_amdgcn_alignbit(x, lk, 32 - cl);         // (x << cl) | (lk >> (32 - cl)), cl in [1,31]
-    x = y >> clz_bias;                                                // keep nb = cl - clz_bias new bits
+    const u32 cl = (u32)__builtin_clz(x);                     // x >= 2^r > 0
+    const u32 y = __builtin_amdgcn_alignbit(x, lk, 32 - cl);  // (x << cl) | (lk >> (32 - cl)), cl in [1,31]
+    x = y >> clz_bias;                                        // keep nb = cl - clz_bias new bits
     const u32 nb = cl - clz_bias;
     lk <<= nb;
     used = nb;
     return e;
 }
 
-__global__ void __launch_bounds__(RF_THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
+// 16 symbols, last first, into one 16-byte register (byte i of the result = symbol i of the block)
+__device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, const u32 *s_dtab, u32 m_log2, u32 slot_mask,
+                                             u32 clz_bias) {
+    u32 ow[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        u32 o = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32 lk = r.look(), ua, ub;
+            const u32 ea = rf_decode_symbol(x, lk, ua, s_dtab, m_log2, slot_mask, clz_bias);
+            const u32 eb = rf_decode_symbol(x, lk, ub, s_dtab, m_log2, slot_mask, clz_bias);
+            r.advance(ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
+            o = __builtin_amdgcn_perm(o, ea, 0x06050400u);  // o = (o << 8) | (ea & 0xFF)
+            o = __builtin_amdgcn_perm(o, eb, 0x06050400u);
+        }
+        ow[d] = o;
+    }
+    r.maybe_refill();
+    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+__global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
                                                                      const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -254,11 +341,12 @@ __global__ void __launch_bounds__(RF_THREADS) rans_decode_fast_kernel(RansFastDe
                                                                      u32 out_cap, u32 *__restrict__ out_lens,
                                                                      u32 *__restrict__ consumed,
                                                                      u32 *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) u32 s_dtab[];
+    __shared__ u32 s_dtab[4096];
+    __shared__ u32 s_ring[32 * RD_THREADS];
     const u32 M = 1u << P.m_log2;
-    for (u32 i = threadIdx.x; i < M; i += RF_THREADS) s_dtab[i] = P.d_dec_tab[i];
+    for (u32 i = threadIdx.x; i < M; i += RD_THREADS) s_dtab[i] = P.d_dec_tab[i];
     __syncthreads();
-    const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
+    const u64 c = (u64)blockIdx.x * RD_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 avail = in_nbits[c];
     u32 st = 0;
@@ -269,7 +357,7 @@ __global__ void __launch_bounds__(RF_THREADS) rans_decode_fast_kernel(RansFastDe
         return;
     }
     DecIn r;
-    r.init(in, in_size_bytes, bit_off[c]);
+    r.init(in, in_size_bytes, bit_off[c], s_ring + threadIdx.x);
     u32 n = r.get(P.size_bits);
     u32 x = r.get(P.nsb);
     out_lens[c] = n;
@@ -278,40 +366,37 @@ __global__ void __launch_bounds__(RF_THREADS) rans_decode_fast_kernel(RansFastDe
         n = 0;
     }
     const u32 st_header = st;
-    const u32 slot_mask = M - 1, clz_bias = 32 - P.nsb;
+    const u32 m_log2 = P.m_log2, slot_mask = M - 1, clz_bias = 32 - P.nsb;
     u8 *dst = out_sym + c * out_stride;
 
-    // symbols come out last-first (rANS.py:291): first the ragged head of the last 16-byte block ...
+    // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
         u32 lk = r.look(), used;
-        const u32 e = rf_decode_symbol(x, lk, used, s_dtab, P.m_log2, slot_mask, clz_bias);
+        const u32 e = rf_decode_symbol(x, lk, used, s_dtab, m_log2, slot_mask, clz_bias);
         r.advance(used);
         dst[--i] = (u8)e;
+        if ((i & 3u) == 0) r.maybe_refill();
     }
-    // ... then whole blocks of 16, assembled in registers and stored with one 16-byte store
-    while (i) {
-        u32 ow[4];
-#pragma unroll
-        for (int d = 3; d >= 0; --d) {
-            u32 o = 0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32 lk = r.look(), ua, ub;
-                const u32 ea = rf_decode_symbol(x, lk, ua, s_dtab, P.m_log2, slot_mask, clz_bias);
-                const u32 eb = rf_decode_symbol(x, lk, ub, s_dtab, P.m_log2, slot_mask, clz_bias);
-                r.advance(ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
-                o = __builtin_amdgcn_perm(o, ea, 0x06050400u);  // o = (o << 8) | (ea & 0xFF)
-                o = __builtin_amdgcn_perm(o, eb, 0x06050400u);
-            }
-            ow[d] = o;
-        }
+    // ... whole 16-byte blocks up to a line boundary ...
+    while (i & 127u) {
+        const uint4 v = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
         i -= 16;
-        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        *reinterpret_cast<uint4 *>(dst + i) = v;
+    }
+    // ... then whole 128-byte lines
+    while (i) {
+        uint4 v[8];
+#pragma unroll
+        for (int b = 7; b >= 0; --b) v[b] = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
+        i -= 128;
+        uint4 *p = reinterpret_cast<uint4 *>(dst + i);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) p[b] = v[b];
     }
     if (r.consumed > avail) st |= SCL_ST_TRUNCATED;
     else if (st_header == 0 && x != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
-    consumed[c] = (u32)r.consumed;
+    consumed[c] = r.consumed;
     if (status) status[c] = st;
 }
 
@@ -383,9 +468,8 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
-    const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    const u32 lds = (1u << m->fdev.m_log2) * sizeof(u32);
-    hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(blocks), dim3(RF_THREADS), lds, st, m->fdev, d_in,
+    const u32 blocks = (u32)((n_chunks + RD_THREADS - 1) / RD_THREADS);
+    hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
                        in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                        d_consumed, d_status);
 }
