@@ -166,19 +166,23 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     u32 x = P.L;
     u32 bad = 0;
 
+    // One 128-byte line per tile.  The loop body is kept to four 16-symbol blocks (about 1.7 K instructions)
+    // and the second half of the line is rotated down, so the hot loop stays well inside the instruction cache.
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-    Line128 bufA, bufB;
-    if (n_lines) bufA.load(src16);
-    for (u32 t = 0; t < n_lines; t += 2) {
-        if (t + 1 < n_lines) bufB.load(src16 + 8 * (t + 1));  // prefetch the next line
+    Line128 cur, nxt;
+    if (n_lines) cur.load(src16);
+#pragma nounroll
+    for (u32 t = 0; t < n_lines; ++t) {
+        if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));  // prefetch the next line while this one is encoded
+#pragma nounroll
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rf_encode16<CHECK_SYM>(bufA.v[i], x, o, bad, s_tab, xshift, m_log2, K);
-        if (t + 1 < n_lines) {
-            if (t + 2 < n_lines) bufA.load(src16 + 8 * (t + 2));
+            for (int i = 0; i < 4; ++i) rf_encode16<CHECK_SYM>(cur.v[i], x, o, bad, s_tab, xshift, m_log2, K);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rf_encode16<CHECK_SYM>(bufB.v[i], x, o, bad, s_tab, xshift, m_log2, K);
+            for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
         }
+        cur = nxt;
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16)  // ragged tail: whole 16-byte blocks, then single symbols
@@ -208,8 +212,8 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
 //   input : the lane's stream arrives in 64-byte blocks (4 back-to-back 16-byte loads, one block prefetched
 //           in registers), is byte-swapped once and parked in a per-lane LDS ring of 32 words ([w][t] layout,
 //           conflict-free); the bit window refills one word at a time from the ring;
-//   output: 128 decoded symbols are assembled in 8 registers and leave as one full line
-//           (8 back-to-back 16-byte stores), last line of the chunk first.
+//   output: 64 decoded symbols are assembled in 4 registers and leave as one 64-byte sector
+//           (4 back-to-back 16-byte stores), end of the chunk first.
 #define RD_THREADS 1024  // one workgroup per CU: 16 KiB slot table + 128 KiB ring
 
 struct DecIn {
@@ -378,21 +382,22 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
         dst[--i] = (u8)e;
         if ((i & 3u) == 0) r.maybe_refill();
     }
-    // ... whole 16-byte blocks up to a line boundary ...
-    while (i & 127u) {
+    // ... whole 16-byte blocks up to a 64-byte boundary ...
+    while (i & 63u) {
         const uint4 v = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
-    // ... then whole 128-byte lines
+    // ... then 64 symbols per iteration: four registers, one burst of four 16-byte stores (a full 64-byte sector)
+#pragma nounroll
     while (i) {
-        uint4 v[8];
+        uint4 a[4];
 #pragma unroll
-        for (int b = 7; b >= 0; --b) v[b] = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
-        i -= 128;
+        for (int b = 3; b >= 0; --b) a[b] = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
+        i -= 64;
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) p[b] = v[b];
+        for (int b = 0; b < 4; ++b) p[b] = a[b];
     }
     if (r.consumed > avail) st |= SCL_ST_TRUNCATED;
     else if (st_header == 0 && x != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
