@@ -28,6 +28,9 @@
 #include "scl_rans_internal.h"
 
 #define RF_THREADS 256
+#ifndef RF_ABLATE
+#define RF_ABLATE 0
+#endif
 
 __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
 
@@ -44,56 +47,85 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 //           t mod 32 for every w, so the scattered ds_write_b32 never conflict), and leave as 64
 //           contiguous bytes (4 back-to-back 16-byte stores) once 16 words are pending.
 #define RF_RING_WORDS 32
+#define RF_RING_BYTES (RF_RING_WORDS * RF_THREADS * 4)  // 32 KiB, placed at LDS offset 0 of the workgroup
 
+// Instruction selection follows profiles/r01_ubench_valu_issue_cost.txt: on gfx950 only
+// v_add/v_sub/v_lshrrev/v_ashrrev/v_and/v_or/v_xor/v_mov (VGPR or literal operands) issue at 32 lanes/clk;
+// compares, carries, left shifts, SDWA, every VOP3 form, the multiplies and any SGPR operand cost twice that.
+// Hence: sign-bit arithmetic instead of compare+carry, model constants as template literals, fields laid out
+// so they need no extraction (k1 rides in the byte v_mad_u32_u24 ignores).
 struct EncOut {
     u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
     u32 nacc;  // number of pending bits
-    u32 wr;    // words completed so far (word j of the stream counted from its END)
-    u32 fl;    // words already stored to memory (multiple of 16 until finish)
-    u32 *ring;  // this thread's column of the LDS ring
+    u32 ra;    // LDS byte address of the ring word that completes next (thread column, wraps inside the ring)
+    u32 fa;    // LDS byte address of the oldest unflushed word
+    u32 pend;  // completed words not yet stored to memory
+    u32 nfl;   // words already stored to memory
     u8 *slot_end;
 
-    __device__ __forceinline__ void init(u32 *ring_, u8 *slot_end_) {
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
         lo = 0;
         nacc = 0;
-        wr = 0;
-        fl = 0;
-        ring = ring_;
+        ra = tid * 4;
+        fa = tid * 4;
+        pend = 0;
+        nfl = 0;
         slot_end = slot_end_;
     }
-    // append `w` bits (v < 2^w, w <= 32) in front of the stream
-    __device__ __forceinline__ void put(u32 v, u32 w) {
-        const u64 t = (u64)v << nacc;
-        lo |= (u32)t;
-        nacc += w;
-        if (nacc >= 32) {
-            ring[(wr & (RF_RING_WORDS - 1)) * RF_THREADS] = __builtin_bswap32(lo);
-            ++wr;
-            lo = (u32)(t >> 32);
-            nacc -= 32;
+    static __device__ __forceinline__ u32 *ring_at(char *lds, u32 byte_addr) {
+        return reinterpret_cast<u32 *>(lds + byte_addr);
+    }
+    // append `w` bits (v < 2^w, w <= 24 unless the accumulator is known to hold < 8 bits) in front of the stream
+    __device__ __forceinline__ void put(char *lds, u32 v, u32 w) {
+        const u32 lo2 = (v << nacc) | lo;
+        const u32 nacc2 = nacc + w;
+        if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
+            *ring_at(lds, ra) = __builtin_bswap32(lo2);
+            ra = (ra + RF_THREADS * 4) & (RF_RING_BYTES - 1);
+            ++pend;
+            lo = v >> (32 - nacc);
+            nacc = nacc2 - 32;
+        } else {
+            lo = lo2;
+            nacc = nacc2;
         }
     }
-    // 16 pending words -> 64 contiguous bytes; call at least every 16 symbols (<= 6 new words)
-    __device__ __forceinline__ void maybe_flush() {
-        if (wr - fl >= 16) {
-            const u32 *r = ring + (fl & 16) * RF_THREADS;
+    __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
+        if (w > 16) {
+            put(lds, v & 0xFFFFu, 16);
+            put(lds, v >> 16, w - 16);
+        } else {
+            put(lds, v, w);
+        }
+    }
+    // 16 pending words -> 64 contiguous bytes; call at least every 32 symbols (<= 12 new words, ring of 32)
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        if (pend >= 16) {
+            const char *r = lds + fa;
             u32 w[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = r[j * RF_THREADS];
-            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(fl + 16));
+            for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * RF_THREADS * 4);
+            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
             p[0] = make_uint4(w[15], w[14], w[13], w[12]);
             p[1] = make_uint4(w[11], w[10], w[9], w[8]);
             p[2] = make_uint4(w[7], w[6], w[5], w[4]);
             p[3] = make_uint4(w[3], w[2], w[1], w[0]);
-            fl += 16;
+            nfl += 16;
+            pend -= 16;
+            fa ^= 16 * RF_THREADS * 4;  // the ring has two halves of 16 words
         }
     }
-    __device__ __forceinline__ u64 finish() {
-        maybe_flush();
+    __device__ __forceinline__ u64 finish(char *lds) {
+        maybe_flush(lds);
         u32 *end32 = reinterpret_cast<u32 *>(slot_end);
-        for (u32 j = fl; j < wr; ++j) end32[-(i64)j - 1] = ring[(j & (RF_RING_WORDS - 1)) * RF_THREADS];
-        if (nacc) end32[-(i64)wr - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
-        return (u64)wr * 32 + nacc;
+        u32 a = fa;
+        for (u32 j = 0; j < pend; ++j) {
+            end32[-(i64)(nfl + j) - 1] = *ring_at(lds, a);
+            a = (a + RF_THREADS * 4) & (RF_RING_BYTES - 1);
+        }
+        const u32 words = nfl + pend;
+        if (nacc) end32[-(i64)words - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
+        return (u64)words * 32 + nacc;
     }
 };
 
@@ -101,39 +133,56 @@ struct EncSym {
     u32 bits, k;
 };
 
-// s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f, s = ceil(log2 f)), so the quotient
-// shift s + k is just m + (x >= thresh).
-__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 s, const uint4 *s_tab, u32 xshift, u32 m_log2) {
-    const uint4 e = s_tab[s];
-    const u32 ge = (x >= e.y) ? 1u : 0u;
-    const u32 k = e.w + ge;
-    const u32 q = rf_umulhi(x << xshift, e.x) >> (m_log2 + ge);
+// One symbol.  `addr` = 16 * symbol (byte offset into the table).  Table entry {rcp, thresh, c, (M-f) | k1 << 24}
+// with k1 = k0 + 1.  MSH = m - (32 - nsb) + 1 so that  q = mulhi(x, rcp) >> (MSH - [x < thresh]).
+// s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f, s = ceil(log2 f)): the quotient shift
+// s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the pre-shift of x disappears.
+template <int MSH_T>
+__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char *tab, u32 msh_rt) {
+    const u32 MSH = MSH_T ? (u32)MSH_T : msh_rt;
+#if RF_ABLATE == 5
+    const uint4 e = make_uint4(0x40000001u + addr, 0x18000000u, addr >> 4, 4000u | (1u << 24));  // ablation: no LDS read
+#elif RF_ABLATE == 2 || RF_ABLATE == 4
+    const uint4 e = *reinterpret_cast<const uint4 *>(tab + (addr & 0x10));  // ablation: conflict-free table reads
+#else
+    const uint4 e = *reinterpret_cast<const uint4 *>(tab + addr);
+#endif
+    const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
+    const u32 k = (e.w >> 24) - neg;
+    const u32 q = rf_umulhi(x, e.x) >> (MSH - neg);
     EncSym r;
     r.bits = __builtin_amdgcn_ubfe(x, 0, k);
     r.k = k;
-    x = (x >> k) + (e.z & 0xFFFFu) + __umul24(q, e.z >> 16);
+    x = __umul24(q, e.w) + (x >> k) + e.z;  // v_mad_u32_u24 reads only the low 24 bits of e.w
     return r;
 }
 
 // 16 symbols (one 16-byte register) -> 8 merged field pairs
-template <bool CHECK_SYM>
-__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, const uint4 *s_tab,
-                                            u32 xshift, u32 m_log2, u32 K) {
+template <bool CHECK_SYM, int MSH_T>
+__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, char *lds, const char *tab,
+                                            u32 msh_rt) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const u32 sa = (wv[d] >> (16 * h)) & 0xFFu;
-            const u32 sb = (wv[d] >> (16 * h + 8)) & 0xFFu;
-            if (CHECK_SYM) bad = max(bad, max(sa, sb));  // largest symbol index seen; compared with K once
-            const EncSym a = rf_encode_symbol(x, sa, s_tab, xshift, m_log2);
-            const EncSym b = rf_encode_symbol(x, sb, s_tab, xshift, m_log2);
-            // the later symbol's field goes in front (more significant side) of the earlier one's
-            o.put(a.bits | (b.bits << a.k), a.k + b.k);
-        }
+        const u32 w = wv[d];
+        const u32 a0 = (w << 4) & 0xFF0u, a1 = (w >> 4) & 0xFF0u, a2 = (w >> 12) & 0xFF0u, a3 = (w >> 20) & 0xFF0u;
+        if (CHECK_SYM) bad = max(max(bad, max(a0, a1)), max(a2, a3));  // 16 * largest symbol index seen
+        const EncSym s0 = rf_encode_symbol<MSH_T>(x, a0, tab, msh_rt);
+        const EncSym s1 = rf_encode_symbol<MSH_T>(x, a1, tab, msh_rt);
+        // the later symbol's field goes in front (more significant side) of the earlier one's
+#if RF_ABLATE == 1 || RF_ABLATE == 4 || RF_ABLATE == 5
+        o.lo ^= s1.bits + s0.bits + s0.k + s1.k;  // ablation: no output path
+#else
+        o.put(lds, (s1.bits << s0.k) | s0.bits, s0.k + s1.k);
+#endif
+        const EncSym s2 = rf_encode_symbol<MSH_T>(x, a2, tab, msh_rt);
+        const EncSym s3 = rf_encode_symbol<MSH_T>(x, a3, tab, msh_rt);
+#if RF_ABLATE == 1 || RF_ABLATE == 4 || RF_ABLATE == 5
+        o.lo ^= s3.bits + s2.bits + s2.k + s3.k;
+#else
+        o.put(lds, (s3.bits << s2.k) | s2.bits, s2.k + s3.k);
+#endif
     }
-    o.maybe_flush();
 }
 
 struct Line128 {
@@ -144,30 +193,32 @@ struct Line128 {
     }
 };
 
-template <bool CHECK_SYM>
+template <bool CHECK_SYM, int MSH_T>
 __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
-                                                                     u64 sym_stride, const u32 *__restrict__ lens,
-                                                                     u32 chunk_len, u64 n_chunks,
-                                                                     u8 *__restrict__ out, u64 out_stride,
-                                                                     u64 *__restrict__ out_bit_off,
-                                                                     u32 *__restrict__ out_nbits,
-                                                                     u32 *__restrict__ status) {
-    __shared__ uint4 s_tab[256];
-    __shared__ u32 s_ring[RF_RING_WORDS * RF_THREADS];
-    s_tab[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+                                                                        u64 sym_stride,
+                                                                        const u32 *__restrict__ lens, u32 chunk_len,
+                                                                        u64 n_chunks, u8 *__restrict__ out,
+                                                                        u64 out_stride, u64 *__restrict__ out_bit_off,
+                                                                        u32 *__restrict__ out_nbits,
+                                                                        u32 *__restrict__ status) {
+    // one LDS block: [0, 32 KiB) word ring, [32 KiB, 36 KiB) symbol table
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_RING_BYTES + 256 * 16];
+    char *lds = s_lds;
+    const char *tab = s_lds + RF_RING_BYTES;
+    reinterpret_cast<uint4 *>(s_lds + RF_RING_BYTES)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    const u32 xshift = 32 - P.nsb, m_log2 = P.m_log2, K = P.K;
+    const u32 msh_rt = P.m_log2 - (32 - P.nsb) + 1;
     EncOut o;
-    o.init(s_ring + threadIdx.x, out + (c + 1) * out_stride);
+    o.init(threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L;
     u32 bad = 0;
 
-    // One 128-byte line per tile.  The loop body is kept to four 16-symbol blocks (about 1.7 K instructions)
-    // and the second half of the line is rotated down, so the hot loop stays well inside the instruction cache.
+    // One 128-byte line per tile.  The loop body is kept to four 16-symbol blocks and the second half of the
+    // line is rotated down, so the hot loop stays well inside the instruction cache.
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
     Line128 cur, nxt;
@@ -178,28 +229,33 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
 #pragma nounroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rf_encode16<CHECK_SYM>(cur.v[i], x, o, bad, s_tab, xshift, m_log2, K);
+            for (int i = 0; i < 4; ++i) {
+                rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, lds, tab, msh_rt);
+                if (i & 1) o.maybe_flush(lds);  // every 32 symbols: <= 12 new words on top of <= 15 pending
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
         }
         cur = nxt;
     }
     u32 i = n_lines << 7;
-    for (; i + 16 <= n; i += 16)  // ragged tail: whole 16-byte blocks, then single symbols
-        rf_encode16<CHECK_SYM>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, s_tab, xshift, m_log2, K);
-    for (; i < n; ++i) {
-        const u32 s = src[i];
-        if (CHECK_SYM) bad = max(bad, s);
-        const EncSym a = rf_encode_symbol(x, s, s_tab, xshift, m_log2);
-        o.put(a.bits, a.k);
-        if ((i & 15u) == 15u) o.maybe_flush();
+    for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
+        rf_encode16<CHECK_SYM, MSH_T>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, lds, tab, msh_rt);
+        o.maybe_flush(lds);
     }
-    o.maybe_flush();
-    o.put(x, P.nsb);
-    u32 st = (CHECK_SYM && bad >= K) ? SCL_ST_SYMBOL : 0u;
+    for (; i < n; ++i) {
+        const u32 a = (u32)src[i] << 4;
+        if (CHECK_SYM) bad = max(bad, a);
+        const EncSym s = rf_encode_symbol<MSH_T>(x, a, tab, msh_rt);
+        o.put(lds, s.bits, s.k);
+        if ((i & 15u) == 15u) o.maybe_flush(lds);
+    }
+    o.maybe_flush(lds);
+    o.put32(lds, x, P.nsb);
+    u32 st = (CHECK_SYM && bad >= (P.K << 4)) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
-    o.put(n, P.size_bits);
-    const u64 total = o.finish();
+    o.put32(lds, n, P.size_bits);
+    const u64 total = o.finish(lds);
     out_bit_off[c] = (c + 1) * out_stride * 8 - total;
     out_nbits[c] = (u32)total;
     if (status) status[c] = st;
@@ -214,18 +270,22 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
 //           conflict-free); the bit window refills one word at a time from the ring;
 //   output: 64 decoded symbols are assembled in 4 registers and leave as one 64-byte sector
 //           (4 back-to-back 16-byte stores), end of the chunk first.
-#define RD_THREADS 1024  // one workgroup per CU: 16 KiB slot table + 128 KiB ring
+// One workgroup of 1024 lanes per CU: [0, 128 KiB) word ring, [128 KiB, 160 KiB) slot table of 8-byte entries
+// {f | sym << 24, slot - c}: v_mad_u32_u24 ignores the symbol byte, so no field needs extracting.
+#define RD_THREADS 1024
+#define RD_RING_BYTES (32 * RD_THREADS * 4)
 
 struct DecIn {
     const uint4 *base;
     u64 n_blocks16;  // readable 16-byte blocks
     u64 next64;      // index of the next 64-byte block to prefetch
     uint4 pf[4];     // prefetched block, next to enter the ring
-    u32 rd, wrw;     // words consumed from / written to the ring
-    u32 *ring;       // this thread's column
+    u32 ra;          // LDS byte address of the next ring word to read (thread column, wraps inside the ring)
+    u32 wa;          // LDS byte address of the ring half that is filled next
+    u32 nrd, nwr;    // words read from / written to the ring
     u32 A, B;        // 64-bit window, big-endian words
     int sh;          // lookahead = low32((A:B) >> sh); sh in [0,31]
-    u32 consumed;    // bits consumed so far
+    u32 bias;        // consumed bits = 32*nrd - sh - bias
 
     __device__ __forceinline__ void load64(u64 j) {
 #pragma unroll
@@ -234,109 +294,118 @@ struct DecIn {
             pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
         }
     }
-    __device__ __forceinline__ void push_pf() {
-        u32 *r = ring + (wrw & 16) * RD_THREADS;
+    __device__ __forceinline__ void push_pf(char *lds) {
+        char *r = lds + wa;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            r[(4 * i + 0) * RD_THREADS] = __builtin_bswap32(pf[i].x);
-            r[(4 * i + 1) * RD_THREADS] = __builtin_bswap32(pf[i].y);
-            r[(4 * i + 2) * RD_THREADS] = __builtin_bswap32(pf[i].z);
-            r[(4 * i + 3) * RD_THREADS] = __builtin_bswap32(pf[i].w);
+            *reinterpret_cast<u32 *>(r + (4 * i + 0) * RD_THREADS * 4) = __builtin_bswap32(pf[i].x);
+            *reinterpret_cast<u32 *>(r + (4 * i + 1) * RD_THREADS * 4) = __builtin_bswap32(pf[i].y);
+            *reinterpret_cast<u32 *>(r + (4 * i + 2) * RD_THREADS * 4) = __builtin_bswap32(pf[i].z);
+            *reinterpret_cast<u32 *>(r + (4 * i + 3) * RD_THREADS * 4) = __builtin_bswap32(pf[i].w);
         }
-        wrw += 16;
+        wa ^= 16 * RD_THREADS * 4;
+        nwr += 16;
     }
-    __device__ __forceinline__ u32 next_word() {
-        const u32 v = ring[(rd & 31u) * RD_THREADS];
-        ++rd;
+    __device__ __forceinline__ u32 next_word(const char *lds) {
+        const u32 v = *reinterpret_cast<const u32 *>(lds + ra);
+        ra = (ra + RD_THREADS * 4) & (RD_RING_BYTES - 1);
+        ++nrd;
         return v;
     }
     // call at least every 16 symbols (<= 6 words consumed in between)
-    __device__ __forceinline__ void maybe_refill() {
-        if (wrw - rd <= 16) {
-            push_pf();
+    __device__ __forceinline__ void maybe_refill(char *lds) {
+        if (nwr - nrd <= 16) {
+            push_pf(lds);
             load64(next64++);
         }
     }
-    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 *ring_) {
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid) {
         base = reinterpret_cast<const uint4 *>(in);
         n_blocks16 = in_size_bytes >> 4;
-        ring = ring_;
         const u64 j0 = bit_off >> 9;
-        wrw = 0;
+        wa = tid * 4;
+        nwr = 0;
         load64(j0);
-        push_pf();
+        push_pf(lds);
         load64(j0 + 1);
-        push_pf();
+        push_pf(lds);
         load64(j0 + 2);
         next64 = j0 + 3;
-        rd = (u32)(bit_off >> 5) & 15u;
+        const u32 w0 = (u32)(bit_off >> 5) & 15u;
+        ra = tid * 4 + w0 * RD_THREADS * 4;
+        nrd = w0;
         const u32 pos = (u32)bit_off & 31u;
-        const u32 first = next_word();
+        const u32 first = next_word(lds);
         if (pos == 0) {
             A = 0;
             B = first;
             sh = 0;
         } else {
             A = first;
-            B = next_word();
+            B = next_word(lds);
             sh = 32 - (int)pos;
         }
-        consumed = 0;
+        bias = 32 * nrd - (u32)sh;  // consumed == 0 here
     }
+    __device__ __forceinline__ u32 consumed() const { return 32 * nrd - (u32)sh - bias; }
     __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
-    __device__ __forceinline__ void advance(u32 nb) {  // nb <= 32
+    __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
         sh -= (int)nb;
-        consumed += nb;
         if (sh < 0) {
             A = B;
-            B = next_word();
+            B = next_word(lds);
             sh += 32;
         }
     }
-    __device__ __forceinline__ u32 get(u32 w) {  // 1 <= w <= 32
+    __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32
         const u32 v = look() >> (32 - w);
-        advance(w);
+        advance(lds, w);
         return v;
     }
 };
 
-// decode one symbol: state update + renormalisation from the 32-bit lookahead `lk` (bits are consumed
-// from its top); returns the packed table entry (symbol in the low byte) and the number of bits used
-__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, const u32 *s_dtab, u32 m_log2,
-                                                u32 slot_mask, u32 clz_bias) {
-    const u32 e = s_dtab[x & slot_mask];
-    x = __umul24(x >> m_log2, (e >> 8) & 0xFFFu) + (e >> 20);
+// decode one symbol: state update + renormalisation from the 32-bit lookahead `lk` (bits are consumed from
+// its top); returns the first table word (symbol in byte 3) and the number of bits used.
+// ML / CB: compile-time m_log2 and 32 - nsb when non-zero, else the run-time values.
+template <int ML_T, int CB_T>
+__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt) {
+    const u32 ML = ML_T ? (u32)ML_T : ml_rt, CB = ML_T ? (u32)CB_T : cb_rt;
+    const uint2 e = *reinterpret_cast<const uint2 *>(tab + ((x << 3) & (((1u << ML) - 1u) << 3)));  // v_and_or with the table base
+    x = __umul24(x >> ML, e.x) + e.y;                         // v_mad_u32_u24 reads the low 24 bits (f) of e.x
     const u32 cl = (u32)__builtin_clz(x);                     // x >= 2^r > 0
     const u32 y = __builtin_amdgcn_alignbit(x, lk, 32 - cl);  // (x << cl) | (lk >> (32 - cl)), cl in [1,31]
-    x = y >> clz_bias;                                        // keep nb = cl - clz_bias new bits
-    const u32 nb = cl - clz_bias;
-    lk <<= nb;
-    used = nb;
-    return e;
+    x = y >> CB;                                              // keep nb = cl - CB new bits
+    used = cl - CB;
+    return e.x;
 }
 
 // 16 symbols, last first, into one 16-byte register (byte i of the result = symbol i of the block)
-__device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, const u32 *s_dtab, u32 m_log2, u32 slot_mask,
-                                             u32 clz_bias) {
+template <int ML_T, int CB_T>
+__device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt) {
     u32 ow[4];
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
         u32 o = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            u32 lk = r.look(), ua, ub;
-            const u32 ea = rf_decode_symbol(x, lk, ua, s_dtab, m_log2, slot_mask, clz_bias);
-            const u32 eb = rf_decode_symbol(x, lk, ub, s_dtab, m_log2, slot_mask, clz_bias);
-            r.advance(ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
-            o = __builtin_amdgcn_perm(o, ea, 0x06050400u);  // o = (o << 8) | (ea & 0xFF)
-            o = __builtin_amdgcn_perm(o, eb, 0x06050400u);
+            const u32 lk = r.look();
+            u32 ua, ub;
+            const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt);
+            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk << ua, ub, tab, ml_rt, cb_rt);
+            r.advance(lds, ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
+            o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
+            o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
+            // the chain through x is serial anyway; without this fence the compiler sinks all the byte inserts
+            // of a 64-symbol iteration to its end, keeps every table word alive until then and spills
+            asm volatile("" : "+v"(o) : : "memory");
         }
         ow[d] = o;
     }
-    r.maybe_refill();
+    r.maybe_refill(lds);
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
+template <int ML_T, int CB_T>
 __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
@@ -345,10 +414,12 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
                                                                      u32 out_cap, u32 *__restrict__ out_lens,
                                                                      u32 *__restrict__ consumed,
                                                                      u32 *__restrict__ status) {
-    __shared__ u32 s_dtab[4096];
-    __shared__ u32 s_ring[32 * RD_THREADS];
+    __shared__ __attribute__((aligned(16))) char s_lds[RD_RING_BYTES + 4096 * 8];
+    char *lds = s_lds;
+    const char *tab = s_lds + RD_RING_BYTES;
     const u32 M = 1u << P.m_log2;
-    for (u32 i = threadIdx.x; i < M; i += RD_THREADS) s_dtab[i] = P.d_dec_tab[i];
+    for (u32 i = threadIdx.x; i < M; i += RD_THREADS)
+        reinterpret_cast<uint2 *>(s_lds + RD_RING_BYTES)[i] = P.d_dec_tab[i];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RD_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -361,30 +432,30 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
         return;
     }
     DecIn r;
-    r.init(in, in_size_bytes, bit_off[c], s_ring + threadIdx.x);
-    u32 n = r.get(P.size_bits);
-    u32 x = r.get(P.nsb);
+    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
+    u32 n = r.get(lds, P.size_bits);
+    u32 x = r.get(lds, P.nsb);
     out_lens[c] = n;
     if (n > out_cap) {
         st |= SCL_ST_CAPACITY;
         n = 0;
     }
     const u32 st_header = st;
-    const u32 m_log2 = P.m_log2, slot_mask = M - 1, clz_bias = 32 - P.nsb;
+    const u32 ml_rt = P.m_log2, cb_rt = 32 - P.nsb;
     u8 *dst = out_sym + c * out_stride;
 
     // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
-        u32 lk = r.look(), used;
-        const u32 e = rf_decode_symbol(x, lk, used, s_dtab, m_log2, slot_mask, clz_bias);
-        r.advance(used);
-        dst[--i] = (u8)e;
-        if ((i & 3u) == 0) r.maybe_refill();
+        u32 used;
+        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, r.look(), used, tab, ml_rt, cb_rt);
+        r.advance(lds, used);
+        dst[--i] = (u8)(e >> 24);
+        if ((i & 3u) == 0) r.maybe_refill(lds);
     }
     // ... whole 16-byte blocks up to a 64-byte boundary ...
     while (i & 63u) {
-        const uint4 v = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
+        const uint4 v = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
@@ -393,15 +464,16 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     while (i) {
         uint4 a[4];
 #pragma unroll
-        for (int b = 3; b >= 0; --b) a[b] = rf_decode16(x, r, s_dtab, m_log2, slot_mask, clz_bias);
+        for (int b = 3; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
         i -= 64;
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
         for (int b = 0; b < 4; ++b) p[b] = a[b];
     }
-    if (r.consumed > avail) st |= SCL_ST_TRUNCATED;
+    const u32 used_bits = r.consumed();
+    if (used_bits > avail) st |= SCL_ST_TRUNCATED;
     else if (st_header == 0 && x != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
-    consumed[c] = r.consumed;
+    consumed[c] = used_bits;
     if (status) status[c] = st;
 }
 
@@ -421,10 +493,11 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     m->fast = 0;
     if (D.b != 1 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || D.m_log2 < 1) return SCL_OK;
     if ((D.RF & (D.RF - 1)) != 0 || D.RF > (1u << 23) || D.nsb > 30 || D.K < 2) return SCL_OK;
+    if (D.m_log2 < 32 - D.nsb) return SCL_OK;  // the encoder folds the pre-shift of x into the quotient shift
     if (m->max_bits_per_symbol > 12) return SCL_OK;
     const u32 M = (u32)D.M, nsb = D.nsb;
     std::vector<uint4> enc(256);
-    std::vector<u32> dec(M);
+    std::vector<uint2> dec(M);
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
         const u32 f = h_freq[src], c = h_cum[src];
@@ -435,14 +508,14 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
         const u64 rcp = ((1ull << (nsb + sh)) + f - 1) / f;             // ceil(2^(nsb+sh)/f) <= 2^(nsb+1)+1
         if (rcp >> 32) return SCL_OK;
         if (sh + k0 != D.m_log2) return SCL_OK;  // cannot happen (see rf_encode_symbol)
-        enc[s] = make_uint4((u32)rcp, (u32)thresh, c | ((M - f) << 16), k0);
+        enc[s] = make_uint4((u32)rcp, (u32)thresh, c, (M - f) | ((k0 + 1) << 24));
     }
     for (u32 s = 0; s < D.K; ++s)
-        for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = s | (h_freq[s] << 8) | (j << 20);
+        for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = make_uint2(h_freq[s] | (s << 24), j);
     hipError_t e = hipMalloc((void **)&m->d_enc_tab, 256 * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_dec_tab, M * sizeof(u32));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_dec_tab, M * sizeof(uint2));
     if (e == hipSuccess) e = hipMemcpy(m->d_enc_tab, enc.data(), 256 * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(m->d_dec_tab, dec.data(), M * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_dec_tab, dec.data(), M * sizeof(uint2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         scl_set_error("rans_model_create: fast-path table upload failed: %s", hipGetErrorString(e));
         return SCL_E_HIP;
@@ -462,19 +535,31 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    if (m->fdev.K < 256)
-        hipLaunchKernelGGL(rans_encode_fast_kernel<true>, dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, d_sym,
-                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
-    else
-        hipLaunchKernelGGL(rans_encode_fast_kernel<false>, dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, d_sym,
-                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+    const int msh = (int)m->fdev.m_log2 - (32 - (int)m->fdev.nsb) + 1;
+#define RF_LAUNCH_ENC(CHECK, MSH)                                                                              \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<CHECK, MSH>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
+                       d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,  \
+                       d_status)
+    // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
+    if (m->fdev.K < 256) {
+        if (msh == 10) RF_LAUNCH_ENC(true, 10); else RF_LAUNCH_ENC(true, 0);
+    } else {
+        if (msh == 10) RF_LAUNCH_ENC(false, 10); else RF_LAUNCH_ENC(false, 0);
+    }
+#undef RF_LAUNCH_ENC
 }
 
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RD_THREADS - 1) / RD_THREADS);
-    hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
-                       in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                       d_consumed, d_status);
+    // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
+    if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29)
+        hipLaunchKernelGGL((rans_decode_fast_kernel<12, 3>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
+                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status);
+    else
+        hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
+                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status);
 }

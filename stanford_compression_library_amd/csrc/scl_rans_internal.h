@@ -21,8 +21,8 @@ struct RansFastDev {
     u32 size_bits;
     u32 m_log2;
     u32 L;
-    const uint4 *d_enc_tab;  // [256] {rcp, thresh, cum | (M-f) << 16, k0}
-    const u32 *d_dec_tab;    // [M]   slot -> sym | f << 8 | (slot - cum) << 20
+    const uint4 *d_enc_tab;  // [256] {rcp, thresh, cum, (M-f) | (k0+1) << 24}
+    const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
 
 struct scl_rans_model {
@@ -35,7 +35,7 @@ struct scl_rans_model {
     u32 *d_freq;
     u32 *d_cum;
     uint4 *d_enc_tab;
-    u32 *d_dec_tab;
+    uint2 *d_dec_tab;
 };
 
 // scl_rans_fast.hip
