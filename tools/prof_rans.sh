@@ -23,3 +23,4 @@ done
 tail -3 $OUT/trace.log
 cat $OUT/kernel_trace_summary.txt
 cat $OUT/pmc_summary.txt
+python3 $REPO/tools/make_traffic_json.py $OUT/pmc_summary.txt $OUT/traffic.json
