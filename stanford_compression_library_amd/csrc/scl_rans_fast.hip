@@ -138,15 +138,8 @@ struct EncSym {
 // s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f, s = ceil(log2 f)): the quotient shift
 // s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the pre-shift of x disappears.
 template <int MSH_T>
-__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char *tab, u32 msh_rt) {
+__device__ __forceinline__ EncSym rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt) {
     const u32 MSH = MSH_T ? (u32)MSH_T : msh_rt;
-#if RF_ABLATE == 5
-    const uint4 e = make_uint4(0x40000001u + addr, 0x18000000u, addr >> 4, 4000u | (1u << 24));  // ablation: no LDS read
-#elif RF_ABLATE == 2 || RF_ABLATE == 4
-    const uint4 e = *reinterpret_cast<const uint4 *>(tab + (addr & 0x10));  // ablation: conflict-free table reads
-#else
-    const uint4 e = *reinterpret_cast<const uint4 *>(tab + addr);
-#endif
     const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
     const u32 k = (e.w >> 24) - neg;
     const u32 q = rf_umulhi(x, e.x) >> (MSH - neg);
@@ -157,31 +150,44 @@ __device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char 
     return r;
 }
 
-// 16 symbols (one 16-byte register) -> 8 merged field pairs
+template <int MSH_T>
+__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char *tab, u32 msh_rt) {
+    return rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + addr), msh_rt);
+}
+
+struct Entries4 {
+    uint4 e[4];
+    __device__ __forceinline__ void load(u32 w, const char *tab) {
+        e[0] = *reinterpret_cast<const uint4 *>(tab + ((w << 4) & 0xFF0u));
+        e[1] = *reinterpret_cast<const uint4 *>(tab + ((w >> 4) & 0xFF0u));
+        e[2] = *reinterpret_cast<const uint4 *>(tab + ((w >> 12) & 0xFF0u));
+        e[3] = *reinterpret_cast<const uint4 *>(tab + ((w >> 20) & 0xFF0u));
+    }
+};
+
+// 16 symbols (one 16-byte register) -> 8 merged field pairs.  The table entries of the next four symbols are
+// fetched from LDS while the current four are coded (the state chain is serial, the table reads are not).
 template <bool CHECK_SYM, int MSH_T>
 __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, char *lds, const char *tab,
                                             u32 msh_rt) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
+    Entries4 cur, nxt;
+    cur.load(wv[0], tab);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const u32 w = wv[d];
-        const u32 a0 = (w << 4) & 0xFF0u, a1 = (w >> 4) & 0xFF0u, a2 = (w >> 12) & 0xFF0u, a3 = (w >> 20) & 0xFF0u;
-        if (CHECK_SYM) bad = max(max(bad, max(a0, a1)), max(a2, a3));  // 16 * largest symbol index seen
-        const EncSym s0 = rf_encode_symbol<MSH_T>(x, a0, tab, msh_rt);
-        const EncSym s1 = rf_encode_symbol<MSH_T>(x, a1, tab, msh_rt);
+        if (d < 3) nxt.load(wv[d + 1], tab);
+        if (CHECK_SYM) {
+            const u32 w = wv[d];
+            bad = max(max(bad, max((w << 4) & 0xFF0u, (w >> 4) & 0xFF0u)), max((w >> 12) & 0xFF0u, (w >> 20) & 0xFF0u));
+        }
+        const EncSym s0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt);
+        const EncSym s1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt);
         // the later symbol's field goes in front (more significant side) of the earlier one's
-#if RF_ABLATE == 1 || RF_ABLATE == 4 || RF_ABLATE == 5
-        o.lo ^= s1.bits + s0.bits + s0.k + s1.k;  // ablation: no output path
-#else
         o.put(lds, (s1.bits << s0.k) | s0.bits, s0.k + s1.k);
-#endif
-        const EncSym s2 = rf_encode_symbol<MSH_T>(x, a2, tab, msh_rt);
-        const EncSym s3 = rf_encode_symbol<MSH_T>(x, a3, tab, msh_rt);
-#if RF_ABLATE == 1 || RF_ABLATE == 4 || RF_ABLATE == 5
-        o.lo ^= s3.bits + s2.bits + s2.k + s3.k;
-#else
+        const EncSym s2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt);
+        const EncSym s3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt);
         o.put(lds, (s3.bits << s2.k) | s2.bits, s2.k + s3.k);
-#endif
+        if (d < 3) cur = nxt;
     }
 }
 
