@@ -36,7 +36,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chunks", type=int, default=262144, help="chunks per GPU")
     ap.add_argument("--chunk-len", type=int, default=4096)
-    ap.add_argument("--table", choices=["t256", "uniform"], default="t256")
+    ap.add_argument("--table", choices=["t256", "uniform", "uniform1"], default="t256",
+                    help="t256: Dirichlet table M=4096; uniform: f=16, M=4096; uniform1: f=1, M=256 (configs[2])")
     ap.add_argument("--coder", choices=["rans", "tans", "range"], default="rans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
@@ -130,7 +131,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    freq = bench_data.t256_table() if args.table == "t256" else bench_data.uniform256_table()
+    freq = {"t256": bench_data.t256_table, "uniform": bench_data.uniform256_table,
+            "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
     model, coder_params = make_model(args, freq)
     n_chunks, chunk_len = args.chunks, args.chunk_len
     sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
@@ -227,7 +229,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"batched 256-symbol static-model {args.coder}: {n_chunks} independent "
                                    f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
-                                   f"table {args.table} (M=4096), i.i.d. symbols p=f/M",
+                                   f"table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M",
                        "coder": args.coder, **coder_params, "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
                        "bits_per_symbol_out": round(bits_per_symbol, 4), "sharding": f"{world} x independent shards"},
             "encode_MBps": round(total_bytes / (enc_ms * 1e-3) / 1e6, 2),

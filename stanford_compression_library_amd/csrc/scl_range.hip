@@ -11,24 +11,7 @@
 // q = (state - low) // (range//M) followed by a search of q in the cumulative table (exact).
 #include <string.h>
 
-#include "scl_common.h"
-
-struct RangeDev {
-    u32 K;
-    u32 P;          // PRECISION
-    u32 size_bits;
-    u32 M;
-    u32 m_log2;     // log2(M) if power of two else 0xFFFFFFFF
-    const u32 *d_freq;
-    const u32 *d_cum;
-    const u8 *d_slot2sym;  // [M] slot -> symbol (decode LUT), null when M is too large
-};
-
-struct scl_range_model {
-    RangeDev dev;
-    u32 *d_freq, *d_cum;
-    u8 *d_slot2sym;
-};
+#include "scl_range_internal.h"
 
 template <typename ST>
 __device__ __forceinline__ ST range_div_M(ST range, const RangeDev &P) {
@@ -211,6 +194,11 @@ extern "C" int scl_range_model_create(const uint32_t *h_freq, uint32_t K, uint32
     m->dev.d_freq = m->d_freq;
     m->dev.d_cum = m->d_cum;
     m->dev.d_slot2sym = m->d_slot2sym;
+    const int rc = range_fast_build_tables(m, h_freq, cum);
+    if (rc != SCL_OK) {
+        scl_range_model_destroy(m);
+        return rc;
+    }
     *out = m;
     return SCL_OK;
 }
@@ -220,6 +208,7 @@ extern "C" void scl_range_model_destroy(scl_range_model *m) {
     if (m->d_freq) (void)hipFree(m->d_freq);
     if (m->d_cum) (void)hipFree(m->d_cum);
     if (m->d_slot2sym) (void)hipFree(m->d_slot2sym);
+    if (m->d_enc_tab) (void)hipFree(m->d_enc_tab);
     delete m;
 }
 
@@ -241,7 +230,10 @@ extern "C" int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d
     if (n_chunks == 0) return SCL_OK;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->dev.P <= 32)
+    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0)
+        range_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                                 d_out_nbits, d_status, (hipStream_t)stream);
+    else if (m->dev.P <= 32)
         hipLaunchKernelGGL(range_encode_kernel<u32>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, m->dev,
                            d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                            d_out_nbits, d_status);
@@ -263,7 +255,10 @@ extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d
     if (n_chunks == 0) return SCL_OK;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->dev.P <= 32)
+    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+        range_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
+    else if (m->dev.P <= 32)
         hipLaunchKernelGGL(range_decode_kernel<u32>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, m->dev,
                            d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                            d_out_lens, d_consumed, d_status);

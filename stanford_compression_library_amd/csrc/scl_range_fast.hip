@@ -1,0 +1,471 @@
+// scl_range_fast.hip -- gfx950 fast path of the batched 32-bit range coder (BASELINE.json configs[2]).
+//
+// Same byte stream as scl_range.hip / reference scl/compressors/range_coder.py:188-207 (encode) and
+// :269-317 (decode).  Serves PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, total_freq = 2^m <= 4096; every other
+// parameter set runs the generic kernels.  Memory access follows the rule established for rANS
+// (scl_rans_fast.hip, profiles/r01_v2 -> r01_v3): a lane only ever moves whole lines / 64-byte sectors.
+//   encode: 128-byte input lines in registers (next line prefetched); emitted bytes are gathered per symbol
+//           (a symbol releases 0..4 bytes), appended to a 64-bit byte accumulator, completed words parked in a
+//           per-lane LDS ring ([word][thread], conflict-free) and stored 64 bytes at a time, front to back.
+//   decode: stream read through the LDS word ring of scl_rans_fast.hip's decoder; the symbol search
+//           max{s : low + c[s]*r <= state} (:232-237) is evaluated as q = (state - low) / r (float estimate +
+//           exact integer correction), then one slot -> symbol LUT read; 64 symbols per 64-byte store burst.
+#include <vector>
+
+#include "scl_range_internal.h"
+
+#define RGE_THREADS 256
+#define RGE_RING_BYTES (32 * RGE_THREADS * 4)
+#define RGD_THREADS 1024
+#define RGD_RING_BYTES (32 * RGD_THREADS * 4)
+#define RG_TOP (1u << 24)
+#define RG_BOTTOM (1u << 16)
+
+// ---------------------------------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------------------------------
+struct RgOut {
+    u64 acc;   // pending bytes in memory order (byte j of the stream tail at bits [8j, 8j+8))
+    u32 cnt;   // number of pending bytes, < 4 between symbols
+    u32 ra;    // LDS byte address of the ring word written next
+    u32 fa;    // LDS byte address of the oldest unflushed word
+    u32 pend;  // completed words not yet in memory
+    u32 nfl;   // words already in memory
+    u32 overflow;
+    u64 cap;   // slot capacity in bytes
+    u8 *slot;
+
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_, u64 cap_) {
+        overflow = 0;
+        cap = cap_;
+        acc = 0;
+        cnt = 0;
+        ra = fa = tid * 4;
+        pend = 0;
+        nfl = 0;
+        slot = slot_;
+    }
+    // append nb (0..4) bytes; byte j of `bytes` (bits [8j, 8j+8)) is the j-th byte in stream order
+    __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nb) {
+        acc |= (u64)bytes << (8 * cnt);
+        cnt += nb;
+        if (cnt >= 4) {
+            *reinterpret_cast<u32 *>(lds + ra) = (u32)acc;
+            ra = (ra + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
+            ++pend;
+            acc >>= 32;
+            cnt -= 4;
+        }
+    }
+    // 16 pending words -> 64 contiguous bytes; call at least every 16 symbols (<= 16 new words, ring of 32)
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        if (pend >= 16) {
+            const char *r = lds + fa;
+            u32 w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * RGE_THREADS * 4);
+            if (4 * (u64)nfl + 64 <= cap) {
+                uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)nfl);
+                p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                p[2] = make_uint4(w[8], w[9], w[10], w[11]);
+                p[3] = make_uint4(w[12], w[13], w[14], w[15]);
+            } else {
+                overflow = 1;
+            }
+            nfl += 16;
+            pend -= 16;
+            fa ^= 16 * RGE_THREADS * 4;
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds) {  // returns total bytes
+        maybe_flush(lds);
+        u32 *w32 = reinterpret_cast<u32 *>(slot);
+        const u64 words = (u64)nfl + pend;
+        if (words * 4 + cnt > cap) {
+            overflow = 1;
+            return words * 4 + cnt;
+        }
+        u32 a = fa;
+        for (u32 j = 0; j < pend; ++j) {
+            w32[nfl + j] = *reinterpret_cast<const u32 *>(lds + a);
+            a = (a + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
+        }
+        for (u32 j = 0; j < cnt; ++j) slot[words * 4 + j] = (u8)(acc >> (8 * j));
+        return words * 4 + cnt;
+    }
+};
+
+__device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
+    const bool settled = ((low ^ (low + range)) < RG_TOP);
+    if (!settled && range >= RG_BOTTOM) return false;
+    if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
+    return true;
+}
+
+// shrink_range (:88-105) + normalize (:107-179) for one symbol; returns the first (up to four) released bytes.
+// A symbol releases at most PRECISION/8 = 4 bytes in practice; callers still run rg_needs_byte afterwards so a
+// fifth byte could never be lost.
+__device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, u32 m_log2, u32 &bytes,
+                                                 u32 &nb) {
+    const u32 r = range >> m_log2;
+    low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
+    range = r * e.y;
+    bytes = 0;
+    nb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool settled = ((low ^ (low + range)) < RG_TOP);
+        if (!settled && range >= RG_BOTTOM) break;
+        if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
+        bytes |= (low >> 24) << (8 * j);
+        ++nb;
+        low <<= 8;
+        range <<= 8;
+    }
+}
+
+struct RgLine128 {
+    uint4 v[8];
+    __device__ __forceinline__ void load(const uint4 *p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+};
+
+__device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range, RgOut &o, u32 &bad, char *lds,
+                                            const char *tab, u32 m_log2) {
+    const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const u32 w = wv[d];
+        const u32 a[4] = {(w << 3) & 0x7F8u, (w >> 5) & 0x7F8u, (w >> 13) & 0x7F8u, (w >> 21) & 0x7F8u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bad = max(bad, a[j]);
+            u32 bytes, nb;
+            rg_encode_symbol(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), m_log2, bytes, nb);
+            o.put_bytes(lds, bytes, nb);
+            while (nb == 4 && rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
+                o.put_bytes(lds, low >> 24, 1);
+                low <<= 8;
+                range <<= 8;
+            }
+        }
+    }
+    o.maybe_flush(lds);
+}
+
+__global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(RangeFastDev P, const u8 *__restrict__ sym,
+                                                                          u64 sym_stride,
+                                                                          const u32 *__restrict__ lens, u32 chunk_len,
+                                                                          u64 n_chunks, u8 *__restrict__ out,
+                                                                          u64 out_stride, u64 *__restrict__ out_bit_off,
+                                                                          u32 *__restrict__ out_nbits,
+                                                                          u32 *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) char s_lds[RGE_RING_BYTES + 256 * 8];
+    char *lds = s_lds;
+    const char *tab = s_lds + RGE_RING_BYTES;
+    reinterpret_cast<uint2 *>(s_lds + RGE_RING_BYTES)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * RGE_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 n = lens ? lens[c] : chunk_len;
+    const u8 *src = sym + c * sym_stride;
+    RgOut o;
+    o.init(threadIdx.x, out + c * out_stride, out_stride);
+    o.put_bytes(lds, __builtin_bswap32(n), 4);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
+    u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
+    const u32 m_log2 = P.m_log2;
+
+    const u32 n_lines = n >> 7;
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
+    RgLine128 cur, nxt;
+    if (n_lines) cur.load(src16);
+#pragma nounroll
+    for (u32 t = 0; t < n_lines; ++t) {
+        if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));
+#pragma nounroll
+        for (int q = 0; q < 4; ++q) {
+            rg_encode16(cur.v[0], low, range, o, bad, lds, tab, m_log2);
+            rg_encode16(cur.v[1], low, range, o, bad, lds, tab, m_log2);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
+        }
+        cur = nxt;
+    }
+    u32 i = n_lines << 7;
+    for (; i + 16 <= n; i += 16)
+        rg_encode16(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, m_log2);
+    for (; i < n; ++i) {
+        const u32 a = (u32)src[i] << 3;
+        bad = max(bad, a);
+        u32 bytes, nb;
+        rg_encode_symbol(low, range, *reinterpret_cast<const uint2 *>(tab + a), m_log2, bytes, nb);
+        o.put_bytes(lds, bytes, nb);
+        while (nb == 4 && rg_needs_byte(low, range)) {
+            o.put_bytes(lds, low >> 24, 1);
+            low <<= 8;
+            range <<= 8;
+        }
+        if ((i & 15u) == 15u) o.maybe_flush(lds);
+    }
+    o.maybe_flush(lds);
+    o.put_bytes(lds, __builtin_bswap32(low), 4);  // flush :181-186: the four bytes of low, most significant first
+    const u64 total_bytes = o.finish(lds);
+    out_bit_off[c] = c * out_stride * 8;
+    out_nbits[c] = (u32)(total_bytes * 8);
+    if (status) status[c] = ((bad >= (P.K << 3)) ? SCL_ST_SYMBOL : 0u) | (o.overflow ? SCL_ST_CAPACITY : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------------
+struct RgIn {  // forward bit reader over a per-lane LDS word ring (same scheme as the rANS fast decoder)
+    const uint4 *base;
+    u64 n_blocks16, next64;
+    uint4 pf[4];
+    u32 ra, wa, nrd, nwr;
+    u32 A, B;
+    int sh;
+    u32 bias;
+
+    __device__ __forceinline__ void load64(u64 j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u64 idx = j * 4 + i;
+            pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void push_pf(char *lds) {
+        char *r = lds + wa;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32 *>(r + (4 * i + 0) * RGD_THREADS * 4) = __builtin_bswap32(pf[i].x);
+            *reinterpret_cast<u32 *>(r + (4 * i + 1) * RGD_THREADS * 4) = __builtin_bswap32(pf[i].y);
+            *reinterpret_cast<u32 *>(r + (4 * i + 2) * RGD_THREADS * 4) = __builtin_bswap32(pf[i].z);
+            *reinterpret_cast<u32 *>(r + (4 * i + 3) * RGD_THREADS * 4) = __builtin_bswap32(pf[i].w);
+        }
+        wa ^= 16 * RGD_THREADS * 4;
+        nwr += 16;
+    }
+    __device__ __forceinline__ u32 next_word(const char *lds) {
+        const u32 v = *reinterpret_cast<const u32 *>(lds + ra);
+        ra = (ra + RGD_THREADS * 4) & (RGD_RING_BYTES - 1);
+        ++nrd;
+        return v;
+    }
+    // call at least every 4 symbols (a symbol consumes <= 4 bytes: 4 words in between)
+    __device__ __forceinline__ void maybe_refill(char *lds) {
+        if (nwr - nrd <= 16) {
+            push_pf(lds);
+            load64(next64++);
+        }
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid) {
+        base = reinterpret_cast<const uint4 *>(in);
+        n_blocks16 = in_size_bytes >> 4;
+        const u64 j0 = bit_off >> 9;
+        wa = tid * 4;
+        nwr = 0;
+        load64(j0);
+        push_pf(lds);
+        load64(j0 + 1);
+        push_pf(lds);
+        load64(j0 + 2);
+        next64 = j0 + 3;
+        const u32 w0 = (u32)(bit_off >> 5) & 15u;
+        ra = tid * 4 + w0 * RGD_THREADS * 4;
+        nrd = w0;
+        const u32 pos = (u32)bit_off & 31u;
+        const u32 first = next_word(lds);
+        if (pos == 0) {
+            A = 0;
+            B = first;
+            sh = 0;
+        } else {
+            A = first;
+            B = next_word(lds);
+            sh = 32 - (int)pos;
+        }
+        bias = 32 * nrd - (u32)sh;
+    }
+    __device__ __forceinline__ u32 consumed() const { return 32 * nrd - (u32)sh - bias; }
+    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
+    __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
+        sh -= (int)nb;
+        if (sh < 0) {
+            A = B;
+            B = next_word(lds);
+            sh += 32;
+        }
+    }
+    __device__ __forceinline__ u32 get32(const char *lds) {
+        const u32 v = look();
+        advance(lds, 32);
+        return v;
+    }
+};
+
+// floor(d / r) for r >= 1: float estimate (exact to +-1 because the quotient is < 2^13 for valid streams)
+// followed by an exact integer correction; quotients that do not fit are clamped by the caller.
+__device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
+    u32 q = (u32)(__uint2float_rz(d) * __frcp_rn(__uint2float_ru(r)));  // never above the true quotient by more than 1
+    u32 t = q * r;
+    if (t > d) {
+        --q;
+        t -= r;
+    }
+    if (d - t >= r) ++q;
+    return q;
+}
+
+// one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
+__device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
+                                                const u8 *s2s, u32 m_log2, u32 slot_max) {
+    const u32 rr = range >> m_log2;
+    u32 q = rg_div(state - low, rr);
+    q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
+    const u32 s = s2s[q];
+    const uint2 e = *reinterpret_cast<const uint2 *>(tab + s * 8);
+    low += e.x * rr;
+    range = rr * e.y;
+    const u32 lk = r.look();
+    u32 nb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool settled = ((low ^ (low + range)) < RG_TOP);
+        if (!settled && range >= RG_BOTTOM) break;
+        if (!settled) range = (0u - low) & (RG_BOTTOM - 1);
+        state = (state << 8) | ((lk >> (24 - 8 * j)) & 0xFFu);
+        ++nb;
+        low <<= 8;
+        range <<= 8;
+    }
+    r.advance(lds, 8 * nb);
+    while (nb == 4 && rg_needs_byte(low, range)) {  // mirror of the encoder's guard
+        state = (state << 8) | (r.look() >> 24);
+        r.advance(lds, 8);
+        low <<= 8;
+        range <<= 8;
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
+                                                                       u64 in_size_bytes,
+                                                                       const u64 *__restrict__ bit_off,
+                                                                       const u32 *__restrict__ in_nbits, u64 n_chunks,
+                                                                       u8 *__restrict__ out_sym, u64 out_stride,
+                                                                       u32 out_cap, u32 *__restrict__ out_lens,
+                                                                       u32 *__restrict__ consumed,
+                                                                       u32 *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) char s_lds[RGD_RING_BYTES + 256 * 8 + 4096];
+    char *lds = s_lds;
+    const char *tab = s_lds + RGD_RING_BYTES;
+    const u8 *s2s = reinterpret_cast<const u8 *>(s_lds + RGD_RING_BYTES + 256 * 8);
+    const u32 M = 1u << P.m_log2;
+    if (threadIdx.x < 256) reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[threadIdx.x] = P.d_enc_tab[threadIdx.x];
+    for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) s_lds[RGD_RING_BYTES + 256 * 8 + i] = (char)P.d_slot2sym[i];
+    __syncthreads();
+    const u64 c = (u64)blockIdx.x * RGD_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 avail = in_nbits[c];
+    u32 st = 0;
+    if (avail < 64) {  // size header + the PRECISION/8 state bytes do not fit
+        out_lens[c] = 0;
+        consumed[c] = 64;
+        if (status) status[c] = SCL_ST_TRUNCATED;
+        return;
+    }
+    RgIn r;
+    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
+    u32 n = r.get32(lds);
+    u32 state = r.get32(lds);  // the first four bytes of the body (:289-291)
+    out_lens[c] = n;
+    if (n > out_cap) {
+        st |= SCL_ST_CAPACITY;
+        n = 0;
+    }
+    u8 *dst = out_sym + c * out_stride;
+    u32 low = 0, range = 0xFFFFFFFFu;
+    const u32 m_log2 = P.m_log2, slot_max = M - 1;
+
+    u32 i = 0;
+    // 64 symbols per iteration: four registers, one burst of four 16-byte stores
+#pragma nounroll
+    for (; i + 64 <= n; i += 64) {
+        uint4 a[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u32 ow[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                u32 o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 s = rg_decode_symbol(low, range, state, r, lds, tab, s2s, m_log2, slot_max);
+                    o |= s << (8 * j);
+                }
+                r.maybe_refill(lds);
+                asm volatile("" : "+v"(o) : : "memory");
+                ow[d] = o;
+            }
+            a[b] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+        uint4 *p = reinterpret_cast<uint4 *>(dst + i);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) p[b] = a[b];
+    }
+    for (; i < n; ++i) {  // ragged tail
+        dst[i] = (u8)rg_decode_symbol(low, range, state, r, lds, tab, s2s, m_log2, slot_max);
+        if ((i & 3u) == 3u) r.maybe_refill(lds);
+    }
+    const u32 used_bits = r.consumed();
+    if (used_bits > avail) st |= SCL_ST_TRUNCATED;
+    consumed[c] = used_bits;
+    if (status) status[c] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_cum) {
+    const RangeDev &D = m->dev;
+    m->fast = 0;
+    if (D.P != 32 || D.size_bits != 32 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || !m->d_slot2sym) return SCL_OK;
+    std::vector<uint2> tab(256);
+    for (u32 s = 0; s < 256; ++s) {
+        const u32 src = s < D.K ? s : 0;
+        tab[s] = make_uint2(h_cum[src], h_freq[src]);
+    }
+    hipError_t e = hipMalloc((void **)&m->d_enc_tab, 256 * sizeof(uint2));
+    if (e == hipSuccess) e = hipMemcpy(m->d_enc_tab, tab.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        scl_set_error("range_model_create: fast-path table upload failed: %s", hipGetErrorString(e));
+        return SCL_E_HIP;
+    }
+    m->fdev.K = D.K;
+    m->fdev.m_log2 = D.m_log2;
+    m->fdev.d_enc_tab = m->d_enc_tab;
+    m->fdev.d_slot2sym = m->d_slot2sym;
+    m->fast = 1;
+    return SCL_OK;
+}
+
+void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                              u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + RGE_THREADS - 1) / RGE_THREADS);
+    hipLaunchKernelGGL(range_encode_fast_kernel, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym, sym_stride,
+                       d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+}
+
+void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
+                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + RGD_THREADS - 1) / RGD_THREADS);
+    hipLaunchKernelGGL(range_decode_fast_kernel, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in, in_size_bytes,
+                       d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                       d_status);
+}
