@@ -1,0 +1,198 @@
+// scl_ans_fast_io.h -- line-granular stream I/O shared by the rANS and tANS fast kernels (same stream layout:
+// produced back to front, read front to back).  Internal to csrc/.
+//
+// Memory granularity rule (profiles/r01_v2_pmc_summary.txt -> r01_v3): with one lane per 4 KiB chunk a CU owns
+// 1024 open cache lines for input and 1024 for output -- more than L1 and, per XCD, the whole L2 -- so a lane
+// must only ever move whole lines / 64-byte sectors:
+//   symbols in : 128 bytes per lane as 8 back-to-back 16-byte loads into registers (Line128);
+//   stream out : completed big-endian words go to a per-lane ring in LDS (word w of thread t at [w][t]: bank =
+//                t mod 32 for every w, so the scattered ds_write_b32 never conflict) and leave as 64 contiguous
+//                bytes (4 back-to-back 16-byte stores) once 16 words are pending (AnsBackWriter);
+//   stream in  : 64-byte blocks (one prefetched in registers), byte-swapped once into the same kind of ring; the
+//                64-bit bit window refills one word at a time from it (AnsBitReader).
+// The ring of a workgroup must start at LDS offset 0 (addresses wrap with a single AND).
+#pragma once
+#include "scl_common.h"
+
+
+// Instruction selection follows profiles/r01_ubench_valu_issue_cost.txt: on gfx950 only
+// v_add/v_sub/v_lshrrev/v_ashrrev/v_and/v_or/v_xor/v_mov (VGPR or literal operands) issue at 32 lanes/clk;
+// compares, carries, left shifts, SDWA, every VOP3 form, the multiplies and any SGPR operand cost twice that.
+// Hence: sign-bit arithmetic instead of compare+carry, model constants as template literals, fields laid out
+// so they need no extraction (k1 rides in the byte v_mad_u32_u24 ignores).
+template <int THREADS>
+struct AnsBackWriter {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
+    u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
+    u32 nacc;  // number of pending bits
+    u32 ra;    // LDS byte address of the ring word that completes next (thread column, wraps inside the ring)
+    u32 fa;    // LDS byte address of the oldest unflushed word
+    u32 pend;  // completed words not yet stored to memory
+    u32 nfl;   // words already stored to memory
+    u8 *slot_end;
+
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
+        lo = 0;
+        nacc = 0;
+        ra = tid * 4;
+        fa = tid * 4;
+        pend = 0;
+        nfl = 0;
+        slot_end = slot_end_;
+    }
+    static __device__ __forceinline__ u32 *ring_at(char *lds, u32 byte_addr) {
+        return reinterpret_cast<u32 *>(lds + byte_addr);
+    }
+    // append `w` bits (v < 2^w, w <= 24 unless the accumulator is known to hold < 8 bits) in front of the stream
+    __device__ __forceinline__ void put(char *lds, u32 v, u32 w) {
+        const u32 lo2 = (v << nacc) | lo;
+        const u32 nacc2 = nacc + w;
+        if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
+            *ring_at(lds, ra) = __builtin_bswap32(lo2);
+            ra = (ra + THREADS * 4) & (RING_BYTES - 1);
+            ++pend;
+            lo = v >> (32 - nacc);
+            nacc = nacc2 - 32;
+        } else {
+            lo = lo2;
+            nacc = nacc2;
+        }
+    }
+    __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
+        if (w > 16) {
+            put(lds, v & 0xFFFFu, 16);
+            put(lds, v >> 16, w - 16);
+        } else {
+            put(lds, v, w);
+        }
+    }
+    // 16 pending words -> 64 contiguous bytes; call at least every 32 symbols (<= 12 new words, ring of 32)
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        if (pend >= 16) {
+            const char *r = lds + fa;
+            u32 w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * THREADS * 4);
+            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
+            p[0] = make_uint4(w[15], w[14], w[13], w[12]);
+            p[1] = make_uint4(w[11], w[10], w[9], w[8]);
+            p[2] = make_uint4(w[7], w[6], w[5], w[4]);
+            p[3] = make_uint4(w[3], w[2], w[1], w[0]);
+            nfl += 16;
+            pend -= 16;
+            fa ^= 16 * THREADS * 4;  // the ring has two halves of 16 words
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds) {
+        maybe_flush(lds);
+        u32 *end32 = reinterpret_cast<u32 *>(slot_end);
+        u32 a = fa;
+        for (u32 j = 0; j < pend; ++j) {
+            end32[-(i64)(nfl + j) - 1] = *ring_at(lds, a);
+            a = (a + THREADS * 4) & (RING_BYTES - 1);
+        }
+        const u32 words = nfl + pend;
+        if (nacc) end32[-(i64)words - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
+        return (u64)words * 32 + nacc;
+    }
+};
+
+struct Line128 {
+    uint4 v[8];
+    __device__ __forceinline__ void load(const uint4 *p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+};
+
+template <int THREADS>
+struct AnsBitReader {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
+    const uint4 *base;
+    u64 n_blocks16;  // readable 16-byte blocks
+    u64 next64;      // index of the next 64-byte block to prefetch
+    uint4 pf[4];     // prefetched block, next to enter the ring
+    u32 ra;          // LDS byte address of the next ring word to read (thread column, wraps inside the ring)
+    u32 wa;          // LDS byte address of the ring half that is filled next
+    u32 nrd, nwr;    // words read from / written to the ring
+    u32 A, B;        // 64-bit window, big-endian words
+    int sh;          // lookahead = low32((A:B) >> sh); sh in [0,31]
+    u32 bias;        // consumed bits = 32*nrd - sh - bias
+
+    __device__ __forceinline__ void load64(u64 j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u64 idx = j * 4 + i;
+            pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void push_pf(char *lds) {
+        char *r = lds + wa;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32 *>(r + (4 * i + 0) * THREADS * 4) = __builtin_bswap32(pf[i].x);
+            *reinterpret_cast<u32 *>(r + (4 * i + 1) * THREADS * 4) = __builtin_bswap32(pf[i].y);
+            *reinterpret_cast<u32 *>(r + (4 * i + 2) * THREADS * 4) = __builtin_bswap32(pf[i].z);
+            *reinterpret_cast<u32 *>(r + (4 * i + 3) * THREADS * 4) = __builtin_bswap32(pf[i].w);
+        }
+        wa ^= 16 * THREADS * 4;
+        nwr += 16;
+    }
+    __device__ __forceinline__ u32 next_word(const char *lds) {
+        const u32 v = *reinterpret_cast<const u32 *>(lds + ra);
+        ra = (ra + THREADS * 4) & (RING_BYTES - 1);
+        ++nrd;
+        return v;
+    }
+    // call at least every 16 symbols (<= 6 words consumed in between)
+    __device__ __forceinline__ void maybe_refill(char *lds) {
+        if (nwr - nrd <= 16) {
+            push_pf(lds);
+            load64(next64++);
+        }
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid) {
+        base = reinterpret_cast<const uint4 *>(in);
+        n_blocks16 = in_size_bytes >> 4;
+        const u64 j0 = bit_off >> 9;
+        wa = tid * 4;
+        nwr = 0;
+        load64(j0);
+        push_pf(lds);
+        load64(j0 + 1);
+        push_pf(lds);
+        load64(j0 + 2);
+        next64 = j0 + 3;
+        const u32 w0 = (u32)(bit_off >> 5) & 15u;
+        ra = tid * 4 + w0 * THREADS * 4;
+        nrd = w0;
+        const u32 pos = (u32)bit_off & 31u;
+        const u32 first = next_word(lds);
+        if (pos == 0) {
+            A = 0;
+            B = first;
+            sh = 0;
+        } else {
+            A = first;
+            B = next_word(lds);
+            sh = 32 - (int)pos;
+        }
+        bias = 32 * nrd - (u32)sh;  // consumed == 0 here
+    }
+    __device__ __forceinline__ u32 consumed() const { return 32 * nrd - (u32)sh - bias; }
+    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
+    __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
+        sh -= (int)nb;
+        if (sh < 0) {
+            A = B;
+            B = next_word(lds);
+            sh += 32;
+        }
+    }
+    __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32
+        const u32 v = look() >> (32 - w);
+        advance(lds, w);
+        return v;
+    }
+};
+

@@ -14,29 +14,7 @@
 // The bit stream is identical to rANS with the same parameters (same layout as scl_rans.hip).
 #include <string.h>
 
-#include "scl_common.h"
-
-struct TansDev {
-    u32 K;
-    u32 size_bits;
-    u32 nsb;
-    u32 m_log2;
-    u32 M, RF, L;  // L = RF*M <= 2^30
-    const u32 *d_freq;
-    const u32 *d_cum;
-    const u32 *d_enc;
-    const u32 *d_nbits;
-    const u32 *d_thresh;
-    const u32 *d_dec_sym;
-    const u32 *d_dec_xs;
-    u32 lds_tables;  // 1: enc / dec tables fit the LDS budget and are staged per workgroup
-};
-
-struct scl_tans_model {
-    TansDev dev;
-    u32 max_bits_per_symbol;
-    u32 *d_freq, *d_cum, *d_enc, *d_nbits, *d_thresh, *d_dec_sym, *d_dec_xs;
-};
+#include "scl_tans_internal.h"
 
 __device__ __forceinline__ u32 tans_find_bin(const u32 *cum, u32 K, u32 slot) {
     u32 lo = 0, hi = K;
@@ -262,6 +240,11 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     m->dev.d_dec_sym = m->d_dec_sym;
     m->dev.d_dec_xs = m->d_dec_xs;
     m->dev.lds_tables = (2 * L * sizeof(u32) <= TANS_LDS_BUDGET) ? 1u : 0u;
+    const int rc = tans_fast_build_tables(m, h_freq, cum);
+    if (rc != SCL_OK) {
+        scl_tans_model_destroy(m);
+        return rc;
+    }
     *out = m;
     return SCL_OK;
 }
@@ -271,6 +254,9 @@ extern "C" void scl_tans_model_destroy(scl_tans_model *m) {
     u32 *ptrs[] = {m->d_freq, m->d_cum, m->d_enc, m->d_nbits, m->d_thresh, m->d_dec_sym, m->d_dec_xs};
     for (u32 *p : ptrs)
         if (p) (void)hipFree(p);
+    if (m->d_fenc_sym) (void)hipFree(m->d_fenc_sym);
+    if (m->d_fenc_tab) (void)hipFree(m->d_fenc_tab);
+    if (m->d_fdec_tab) (void)hipFree(m->d_fdec_tab);
     delete m;
 }
 
@@ -315,6 +301,13 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
                 "tans_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "tans_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
+    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+        out_stride >= scl_tans_slot_bytes(m, chunk_len)) {
+        tans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                                d_out_nbits, d_status, (hipStream_t)stream);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (768 + (m->dev.lds_tables ? m->dev.L : 0)) * sizeof(u32);
@@ -333,6 +326,12 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                 "tans_decode_batch: null pointer argument");
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "tans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
+    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
+        tans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (m->dev.lds_tables ? 2 * m->dev.L : 4) * sizeof(u32);
