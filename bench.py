@@ -38,7 +38,8 @@ def parse_args():
     ap.add_argument("--chunk-len", type=int, default=4096)
     ap.add_argument("--table", choices=["t256", "uniform", "uniform1"], default="t256",
                     help="t256: Dirichlet table M=4096; uniform: f=16, M=4096; uniform1: f=1, M=256 (configs[2])")
-    ap.add_argument("--coder", choices=["rans", "tans", "range"], default="rans")
+    ap.add_argument("--coder", choices=["rans", "tans", "range", "aec"], default="rans")
+    ap.add_argument("--aec-K", type=int, default=16, help="alphabet of the order-1 adaptive arithmetic coder (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
     ap.add_argument("--sym-pad", type=int, default=0, help="experiment: extra bytes between input rows")
@@ -52,7 +53,17 @@ def make_model(args, freq):
         return models.RansModel(freq.tolist(), 1 << 16, 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1 << 16)
     if args.coder == "tans":
         return models.TansModel(freq.tolist(), 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1)
+    if args.coder == "aec":
+        K = args.aec_K
+        return (models.AecModel(backend_lib_consts()["MODEL_ORDERK"], None, K, 1, 1 << 30, 32, 32),
+                dict(PRECISION=32, model=f"AdaptiveOrderKFreqModel(k=1, K={K})"))
     return models.RangeModel(freq.tolist(), 32, 32), dict(PRECISION=32)
+
+
+def backend_lib_consts():
+    from stanford_compression_library_amd.backend import lib
+
+    return {"MODEL_ORDERK": lib.MODEL_ORDERK}
 
 
 def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
@@ -135,7 +146,12 @@ def main():
             "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
     model, coder_params = make_model(args, freq)
     n_chunks, chunk_len = args.chunks, args.chunk_len
-    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
+    if args.coder == "aec":
+        # configs[3]: Markov-1 source (S4 of SURVEY 8d); 256 distinct chunks generated on the host, tiled to the batch
+        base = np.stack([bench_data.markov1_host(args.aec_K, chunk_len, seed=4 + 1000 * rank + i) for i in range(256)])
+        sym = torch.from_numpy(base).to(dev).repeat((n_chunks + 255) // 256, 1)[:n_chunks].contiguous()
+    else:
+        sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
     if args.sym_pad:
         padded = torch.zeros((n_chunks, chunk_len + args.sym_pad), dtype=torch.uint8, device=dev)
         padded[:, :chunk_len] = sym
@@ -227,9 +243,11 @@ def main():
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"batched 256-symbol static-model {args.coder}: {n_chunks} independent "
+            "config": {"workload": f"batched {args.coder}: {n_chunks} independent "
                                    f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
-                                   f"table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M",
+                                   + (f"256-symbol static table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M"
+                                      if args.coder != "aec"
+                                      else f"order-1 adaptive model, K={args.aec_K}, Markov-1 source"),
                        "coder": args.coder, **coder_params, "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
                        "bits_per_symbol_out": round(bits_per_symbol, 4), "sharding": f"{world} x independent shards"},
             "encode_MBps": round(total_bytes / (enc_ms * 1e-3) / 1e6, 2),

@@ -200,6 +200,11 @@ int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const
                         uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
                         uint64_t *d_out_byte_offset, void *d_scratch, void *stream);
 
+/* ---- model construction helper (row f3): symbol histogram ------------------------------------------ */
+/* d_counts[256] (uint64) += number of occurrences of every byte value in d_sym[0..n).  The caller zeroes
+   d_counts.  Equals DataBlock.get_counts() (scl/core/data_block.py:37-62) for uint8 data. */
+int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_counts, void *stream);
+
 /* ---- host convenience (one chunk, host buffers; allocates, copies, runs N=1, synchronises) --- */
 /* These back the drop-in encode_block / decode_block of the Python classes.  h_out receives the
    left-aligned stream (what BitArray.tobytes() would give); *nbits its length. */

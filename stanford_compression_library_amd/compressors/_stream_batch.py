@@ -1,0 +1,87 @@
+"""Batched form of the block loop ``DataEncoder.encode`` / ``DataDecoder.decode`` -- row f2 of the scope table.
+
+The reference walks a stream block by block: ``get_block`` -> ``encode_block`` -> ``write_block`` (one framed
+record per block, scl/core/data_encoder_decoder.py:57-69 and :118-144).  The static-model coders make every block
+independent, so here the whole stream becomes ONE batched launch (one lane per block) followed by the device-side
+framing pass (``scl_streams_compact`` with ``SCL_COMPACT_FRAMED``), and the file bytes are written in one go.
+The resulting file is byte-identical to the per-block loop (and to the reference's ``EncodedBlockWriter``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..backend.models import compact
+
+
+class BatchedStreamEncoderMixin:
+    """expects ``self._batch_model()`` -> (device model, symbol->index dict)"""
+
+    def encode(self, data_stream, block_size: int, encode_writer):
+        import torch
+
+        blocks = []
+        while True:
+            blk = data_stream.get_block(block_size)
+            if blk is None:
+                break
+            blocks.append(blk)
+        if not blocks:
+            return
+        model, index_of = self._batch_model()
+        n = len(blocks)
+        width = (block_size + 15) // 16 * 16
+        sym = np.zeros((n, width), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        for i, blk in enumerate(blocks):
+            data = blk.data_list
+            sym[i, :len(data)] = np.fromiter((index_of[s] for s in data), dtype=np.uint8, count=len(data))
+            lens[i] = len(data)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        enc = model.encode_batch(torch.from_numpy(sym).to(dev)[:, :block_size] if width == block_size
+                                 else torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev),
+                                 out_stride=model.slot_bytes(block_size))
+        framed, offs = compact(enc, framed=True)
+        status = enc.status.cpu().numpy()
+        assert not status.any(), f"device reported chunk status {status[status != 0][:4]}"
+        encode_writer.write_framed_bytes(framed[: int(offs[-1].item())].cpu().numpy().tobytes())
+
+
+class BatchedStreamDecoderMixin:
+    """expects ``self._batch_model()`` -> (device model, alphabet list) and ``self._size_bits``"""
+
+    def decode(self, encode_reader, output_stream):
+        import torch
+
+        from ..core.data_block import DataBlock
+
+        raw = np.frombuffer(encode_reader.file_reader.read(), dtype=np.uint8)
+        if raw.size == 0:
+            return
+        # walk the 4-byte block headers on the host (one per block); the payload bits stay where they are
+        offs, nbits, pos = [], [], 0
+        while pos < raw.size:
+            payload = int.from_bytes(raw[pos:pos + 4].tobytes(), "big")
+            assert pos + 4 + payload <= raw.size, "truncated block file"
+            pad = int(raw[pos + 4]) >> 5
+            offs.append(8 * (pos + 4) + 3 + pad)
+            nbits.append(8 * payload - 3 - pad)
+            pos += 4 + payload
+        model, alphabet = self._batch_model()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.zeros(raw.size + 64, dtype=torch.uint8, device=dev)
+        buf[: raw.size] = torch.from_numpy(raw.copy()).to(dev)
+        # block sizes come from each stream's own header; capacity = the largest header value
+        sb = self._size_bits
+        cap = 0
+        for o in offs:
+            bits = np.unpackbits(raw[o // 8:(o + sb + 7) // 8 + 1])[o % 8:o % 8 + sb]
+            cap = max(cap, int("".join(map(str, bits.tolist())), 2))
+        sym, lens, used, status = model.decode_batch(buf, torch.tensor(offs, dtype=torch.int64, device=dev),
+                                                     torch.tensor(nbits, dtype=torch.int32, device=dev), max(cap, 1))
+        torch.cuda.synchronize()
+        status = status.cpu().numpy()
+        assert not status.any(), f"device reported chunk status {status[status != 0][:4]}"
+        used, lens, sym = used.cpu().numpy(), lens.cpu().numpy(), sym.cpu().numpy()
+        for i in range(len(offs)):
+            assert int(used[i]) == nbits[i]  # num_bits_consumed == len(encoded_block), data_encoder_decoder.py:141
+            output_stream.write_block(DataBlock([alphabet[j] for j in sym[i, :lens[i]].tolist()]))

@@ -17,6 +17,7 @@ from ..core.data_encoder_decoder import DataDecoder, DataEncoder
 from ..core.prob_dist import Frequencies
 from ..utils.bitarray_utils import BitArray, get_bit_width
 from ._common import check_alphabet, indices_to_block, symbols_to_indices
+from ._stream_batch import BatchedStreamDecoderMixin, BatchedStreamEncoderMixin
 
 __all__ = ["rANSParams", "rANSEncoder", "rANSDecoder"]
 
@@ -55,9 +56,12 @@ class rANSParams:
         return model
 
 
-class rANSEncoder(DataEncoder):
+class rANSEncoder(BatchedStreamEncoderMixin, DataEncoder):
     def __init__(self, rans_params: rANSParams):
         self.params = rans_params
+
+    def _batch_model(self):
+        return self.params._device_model(), self.params._index_of
 
     def encode_block(self, data_block: DataBlock) -> BitArray:
         """[size | final state | per-symbol fields, last symbol first] -- rANS.py:186-210."""
@@ -68,9 +72,13 @@ class rANSEncoder(DataEncoder):
         return BitArray.from_packed(packed, nbits)
 
 
-class rANSDecoder(DataDecoder):
+class rANSDecoder(BatchedStreamDecoderMixin, DataDecoder):
     def __init__(self, rans_params: rANSParams):
         self.params = rans_params
+        self._size_bits = rans_params.DATA_BLOCK_SIZE_BITS
+
+    def _batch_model(self):
+        return self.params._device_model(), self.params._alphabet
 
     def decode_block(self, encoded_bitarray: BitArray) -> Tuple[DataBlock, int]:
         """-> (DataBlock, num_bits_consumed); trailing bits are ignored -- rANS.py:270-297.

@@ -14,6 +14,7 @@ from ..core.data_encoder_decoder import DataDecoder, DataEncoder
 from ..core.prob_dist import Frequencies
 from ..utils.bitarray_utils import BitArray
 from ._common import check_alphabet, indices_to_block, symbols_to_indices
+from ._stream_batch import BatchedStreamDecoderMixin, BatchedStreamEncoderMixin
 
 __all__ = ["RangeCoderParams", "RangeEncoder", "RangeDecoder"]
 
@@ -49,7 +50,10 @@ class _RangeBase:
         return self._model
 
 
-class RangeEncoder(_RangeBase, DataEncoder):
+class RangeEncoder(BatchedStreamEncoderMixin, _RangeBase, DataEncoder):
+    def _batch_model(self):
+        return self._device_model(), self._index_of
+
     def encode_block(self, data_block: DataBlock) -> BitArray:
         """[size | renormalisation bytes | PRECISION/8 flush bytes] -- range_coder.py:188-207."""
         model = self._device_model()
@@ -59,7 +63,11 @@ class RangeEncoder(_RangeBase, DataEncoder):
         return BitArray.from_packed(packed, nbits)
 
 
-class RangeDecoder(_RangeBase, DataDecoder):
+class RangeDecoder(BatchedStreamDecoderMixin, _RangeBase, DataDecoder):
+    def _batch_model(self):
+        self._size_bits = self.params.DATA_BLOCK_SIZE_BITS
+        return self._device_model(), self._alphabet
+
     def decode_block(self, encoded_bitarray: BitArray) -> Tuple[DataBlock, int]:
         """-> (DataBlock, num_bits_consumed incl. the size header) -- range_coder.py:269-317."""
         model = self._device_model()

@@ -16,6 +16,7 @@ from ..core.data_encoder_decoder import DataDecoder, DataEncoder
 from ..utils.bitarray_utils import BitArray
 from ..utils.misc_utils import is_power_of_two
 from ._common import check_alphabet, indices_to_block, symbols_to_indices
+from ._stream_batch import BatchedStreamDecoderMixin, BatchedStreamEncoderMixin
 from .rANS import rANSParams
 
 __all__ = ["tANSParams", "tANSEncoder", "tANSDecoder"]
@@ -51,11 +52,14 @@ class tANSParams(rANSParams):
         return tabs
 
 
-class tANSEncoder(DataEncoder):
+class tANSEncoder(BatchedStreamEncoderMixin, DataEncoder):
     """Table-driven encoder; the three encoder tables of the reference are views of the device tables."""
 
     def __init__(self, tans_params: tANSParams):
         self.params = tans_params
+
+    def _batch_model(self):
+        return self.params._device_model(), self.params._index_of
 
     @property
     def base_encode_step_table(self) -> dict:
@@ -88,9 +92,13 @@ class tANSEncoder(DataEncoder):
         return BitArray.from_packed(packed, nbits)
 
 
-class tANSDecoder(DataDecoder):
+class tANSDecoder(BatchedStreamDecoderMixin, DataDecoder):
     def __init__(self, tans_params: tANSParams):
         self.params = tans_params
+        self._size_bits = tans_params.DATA_BLOCK_SIZE_BITS
+
+    def _batch_model(self):
+        return self.params._device_model(), self.params._alphabet
 
     @property
     def base_decode_step_table(self) -> dict:

@@ -194,6 +194,49 @@ extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_of
     return SCL_OK;
 }
 
+// ---- symbol histogram (row f3) ----------------------------------------------------------------------
+// 16 bytes per lane per load, per-wave private histograms in LDS (4 copies per workgroup: a wave's 64 lanes
+// collide on hot symbols, so sub-histograms by wave cut the ds_add serialisation), one global atomic per bin
+// per workgroup at the end.
+__global__ void __launch_bounds__(256) histogram_u8_kernel(const uint4 *__restrict__ sym16, u64 n16,
+                                                          const u8 *__restrict__ tail, u32 n_tail,
+                                                          unsigned long long *__restrict__ counts) {
+    __shared__ u32 s_h[4][256];
+    for (u32 i = threadIdx.x; i < 1024; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    u32 *h = s_h[threadIdx.x >> 6];
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n16; i += (u64)gridDim.x * 256) {
+        const uint4 v = sym16[i];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            atomicAdd(&h[w[d] & 0xFF], 1u);
+            atomicAdd(&h[(w[d] >> 8) & 0xFF], 1u);
+            atomicAdd(&h[(w[d] >> 16) & 0xFF], 1u);
+            atomicAdd(&h[w[d] >> 24], 1u);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n_tail) atomicAdd(&h[tail[threadIdx.x]], 1u);
+    __syncthreads();
+    const u32 total = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    if (total) atomicAdd(&counts[threadIdx.x], (unsigned long long)total);
+}
+
+extern "C" int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_counts, void *stream) {
+    SCL_REQUIRE(d_counts && (d_sym || n == 0), "histogram_u8: null pointer argument");
+    SCL_REQUIRE(((uintptr_t)d_sym & 15) == 0, "histogram_u8: d_sym must be 16-byte aligned");
+    if (n == 0) return SCL_OK;
+    const u64 n16 = n >> 4;
+    u32 blocks = (u32)((n16 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;  // grid-stride above 8 workgroups per CU
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(histogram_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4 *>(d_sym), n16, d_sym + (n16 << 4), (u32)(n & 15),
+                       reinterpret_cast<unsigned long long *>(d_counts));
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
 // ---- host convenience drivers -----------------------------------------------------------------------
 extern "C" int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
                                           uint64_t *n_out) {

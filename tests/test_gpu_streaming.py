@@ -1,0 +1,92 @@
+"""GPU: rows f1-f3 -- the batched block loop (encode_file / decode_file), device-side framing and the histogram.
+File bytes must equal what the reference's per-block loop + EncodedBlockWriter produce (checked here against
+the oracle's streams framed by our host-side Padder/HeaderHandler, which test_streams_framing.py pins)."""
+import os
+
+import numpy as np
+import pytest
+
+import scl_oracle as orc
+from stanford_compression_library_amd.backend import lib as backend_lib
+from stanford_compression_library_amd.backend.modeling import frequencies_from_counts, histogram_u8, normalize_counts
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.data_stream import Uint8FileDataStream
+from stanford_compression_library_amd.core.encoded_stream import EncodedBlockReader, EncodedBlockWriter, HeaderHandler, Padder
+from stanford_compression_library_amd.core.prob_dist import Frequencies
+from stanford_compression_library_amd.utils.bitarray_utils import BitArray
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _text(n, seed):
+    rng = np.random.default_rng(seed)
+    return "".join(rng.choice(list("abcdefgh \n"), size=n, p=[.3, .2, .1, .1, .05, .05, .05, .05, .08, .02]))
+
+
+def _framed(bits_list):
+    out = b""
+    for packed, nb in bits_list:
+        out += HeaderHandler.add_header(Padder.add_byte_padding(BitArray.from_packed(packed, nb))).tobytes()
+    return out
+
+
+def test_encode_file_decode_file_rans(tmp_path):
+    """text file -> framed file -> text file, one batched launch per direction; the framed file equals the
+    per-block reference layout"""
+    backend_lib.require_device()
+    text = _text(25_123, 1)
+    src, enc_path, dec_path = (os.path.join(tmp_path, n) for n in ("in.txt", "enc.bin", "out.txt"))
+    open(src, "w").write(text)
+    alphabet = list("abcdefgh \n")
+    counts = [max(1, text.count(ch)) for ch in alphabet]
+    fr = Frequencies(dict(zip(alphabet, normalize_counts(counts, 1024).tolist())))
+    params = rANSParams(fr)
+    rANSEncoder(params).encode_file(src, enc_path, block_size=1000)
+    # expected bytes: oracle stream of every 1000-character block, framed like EncodedBlockWriter
+    idx = np.array([alphabet.index(ch) for ch in text], dtype=np.uint8)
+    expect = _framed([orc.rans_encode(idx[i:i + 1000], fr.freq_list) for i in range(0, idx.size, 1000)])
+    assert open(enc_path, "rb").read() == expect
+    rANSDecoder(params).decode_file(enc_path, dec_path)
+    assert open(dec_path).read() == text
+
+
+@pytest.mark.parametrize("coder", ["tans", "range"])
+def test_stream_encode_matches_block_loop(coder, tmp_path):
+    """the batched `encode` of a byte stream == calling encode_block per block and writing with EncodedBlockWriter"""
+    data = np.random.default_rng(3).choice(256, size=10_000, p=np.r_[np.full(128, 0.006), np.full(128, 0.0018125)]).tolist()
+    fr = frequencies_from_counts(np.bincount(data, minlength=256), 4096)
+    path = os.path.join(tmp_path, "in.bin")
+    open(path, "wb").write(bytes(data))
+    if coder == "tans":
+        p = tANSParams(fr, RANGE_FACTOR=1)
+        enc, dec = tANSEncoder(p), tANSDecoder(p)
+    else:
+        enc, dec = RangeEncoder(RangeCoderParams(), fr), RangeDecoder(RangeCoderParams(), fr)
+    a, b = os.path.join(tmp_path, "a.bin"), os.path.join(tmp_path, "b.bin")
+    with Uint8FileDataStream(path, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 777, w)                      # one launch for all 13 blocks (last one ragged)
+    with EncodedBlockWriter(b) as w:
+        for i in range(0, len(data), 777):
+            w.write_block(enc.encode_block(DataBlock(data[i:i + 777])))
+    assert open(a, "rb").read() == open(b, "rb").read()
+    out = os.path.join(tmp_path, "out.bin")
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == bytes(data)
+
+
+def test_histogram_equals_get_counts():
+    backend_lib.require_device()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 15, 16, 17, 4096, 1_000_003):
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        if n > 100:
+            data[: n // 2] = 7  # a hot symbol: every lane of a wave hits the same bin
+        got = histogram_u8(torch.from_numpy(data).cuda())
+        ref = DataBlock(data.tolist()).get_counts() if n else {}
+        assert got.sum() == n and all(got[s] == c for s, c in ref.items())
+        assert np.array_equal(got, np.bincount(data, minlength=256))

@@ -152,3 +152,22 @@ def test_freq_models_host_mirror():
     assert ok.freqs_kplus1_tuple[2, 1] == 2 and ok.freqs_current.freq_dict == {0: 1, 1: 1, 2: 1}
     spec = copy.deepcopy(ok).device_spec()
     assert (spec["kind"], spec["K"], spec["k"]) == (2, 3, 1)
+
+
+# ---- frequency normaliser (row f3) ------------------------------------------------------------------------
+def test_normalize_counts_properties():
+    from stanford_compression_library_amd.backend.modeling import frequencies_from_counts, normalize_counts
+
+    rng = np.random.default_rng(0)
+    for total in (256, 4096, 65536):
+        for _ in range(20):
+            counts = rng.integers(0, 10_000, 256) * (rng.random(256) < 0.7)
+            counts[rng.integers(0, 256)] += 1
+            f = normalize_counts(counts, total)
+            assert f.sum() == total and ((f > 0) == (counts > 0)).all()
+            # proportionality: never off by more than one unit plus the guaranteed floor of 1
+            ideal = counts * (total / counts.sum())
+            assert np.all(np.abs(f - ideal) <= 1.0 + (counts > 0))
+    assert normalize_counts([5, 0, 1, 94], 16).tolist() == [2, 0, 1, 13]
+    fr = frequencies_from_counts([0, 3, 0, 1], 4)
+    assert fr.freq_dict == {1: 3, 3: 1}
