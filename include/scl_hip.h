@@ -94,7 +94,8 @@ int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_fac
                           uint32_t num_bits_out, uint32_t size_bits, scl_rans_model **out);
 void scl_rans_model_destroy(scl_rans_model *m);
 int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info);
-/* bytes a slot must have so that any block of n symbols fits (multiple of 16) */
+/* bytes a slot must have so that any block of n symbols fits (multiple of 128: whole cache lines, so the
+   64-byte store bursts of the fast kernels never straddle a sector) */
 uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols);
 
 /* chunk c reads symbols d_sym[c*sym_stride .. +len_c) with len_c = d_lens ? d_lens[c] : chunk_len */

@@ -400,7 +400,7 @@ extern "C" uint64_t scl_aec_slot_bytes(const scl_aec_model *m, uint64_t n_symbol
     // every symbol narrows the interval by at most a factor 1/QTR-ish: <= PRECISION bits per symbol, plus
     // header, termination and pending bits
     const u64 bits = (u64)m->dev.size_bits + n_symbols * (u64)m->dev.P + 2 * m->dev.P + 8;
-    return scl_round_up((bits + 7) / 8 + 4, 16);
+    return scl_round_up((bits + 7) / 8 + 4, 128);
 }
 
 extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chunks) {

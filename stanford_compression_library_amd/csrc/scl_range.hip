@@ -216,7 +216,7 @@ extern "C" uint64_t scl_range_slot_bytes(const scl_range_model *m, uint64_t n_sy
     if (!m) return 0;
     // a symbol can shift out at most P/8 bytes (range drops from 2^P to >= 1), typically log2(M/f)/8
     const u64 bytes = (m->dev.size_bits + 7) / 8 + n_symbols * (m->dev.P / 8) + m->dev.P / 8;
-    return scl_round_up(bytes + 4, 16);
+    return scl_round_up(bytes + 4, 128);
 }
 
 extern "C" int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d_sym, uint64_t sym_stride,

@@ -238,7 +238,7 @@ extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info)
 extern "C" uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols) {
     if (!m) return 0;
     const u64 bits = (u64)m->dev.size_bits + m->dev.nsb + n_symbols * (u64)m->max_bits_per_symbol;
-    return scl_round_up((bits + 7) / 8 + 4, 16);
+    return scl_round_up((bits + 7) / 8 + 4, 128);
 }
 
 static int check_batch_args(const char *what, const void *m, const void *a, const void *b, const void *c,

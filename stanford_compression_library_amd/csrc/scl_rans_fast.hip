@@ -284,22 +284,25 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
         dst[--i] = (u8)(e >> 24);
         if ((i & 3u) == 0) r.maybe_refill(lds);
     }
-    // ... whole 16-byte blocks up to a 64-byte boundary ...
-    while (i & 63u) {
+    // ... whole 16-byte blocks up to a line boundary ...
+    while (i & 127u) {
         const uint4 v = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
-    // ... then 64 symbols per iteration: four registers, one burst of four 16-byte stores (a full 64-byte sector)
+    // ... then one full 128-byte line per iteration: eight registers, one burst of eight 16-byte stores
 #pragma nounroll
     while (i) {
-        uint4 a[4];
+        uint4 a[8];
 #pragma unroll
-        for (int b = 3; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
-        i -= 64;
+        for (int b = 7; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
+        i -= 128;
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
+#if RF_ABLATE == 11
+        if (i == 0)  // ablation: only the last burst is stored
+#endif
 #pragma unroll
-        for (int b = 0; b < 4; ++b) p[b] = a[b];
+        for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     const u32 used_bits = r.consumed();
     if (used_bits > avail) st |= SCL_ST_TRUNCATED;

@@ -277,7 +277,7 @@ extern "C" int scl_tans_model_info(const scl_tans_model *m, scl_rans_info *info)
 extern "C" uint64_t scl_tans_slot_bytes(const scl_tans_model *m, uint64_t n_symbols) {
     if (!m) return 0;
     const u64 bits = (u64)m->dev.size_bits + m->dev.nsb + n_symbols * (u64)m->max_bits_per_symbol;
-    return scl_round_up((bits + 7) / 8 + 4, 16);
+    return scl_round_up((bits + 7) / 8 + 4, 128);
 }
 
 extern "C" int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, uint32_t *h_nbits, uint32_t *h_thresh,

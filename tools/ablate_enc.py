@@ -9,8 +9,13 @@ freq = bench_data.t256_table()
 model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
 n_chunks, chunk_len = int(os.environ.get('NCHUNKS', 262144)), 4096
 sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
-enc = model.alloc_encoded(n_chunks, chunk_len, dev)
-dec = model.alloc_decoded(n_chunks, chunk_len, dev)
+PAD = int(os.environ.get('PAD', 0))
+if PAD:
+    padded = torch.zeros((n_chunks, chunk_len + PAD), dtype=torch.uint8, device=dev)
+    padded[:, :chunk_len] = sym
+    sym = padded[:, :chunk_len]
+enc = model.alloc_encoded(n_chunks, chunk_len, dev, out_stride=int(os.environ.get('SLOT', 0)) or None)
+dec = model.alloc_decoded(n_chunks, chunk_len + PAD, dev)
 for _ in range(2):
     model.encode_batch(sym, out=enc); model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec)
 torch.cuda.synchronize()
@@ -20,4 +25,4 @@ for _ in range(5):
     e[0].record(); model.encode_batch(sym, out=enc); e[1].record()
     model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
     torch.cuda.synchronize(); te += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
-print(f"{os.environ.get('ABL','base')} chunks={n_chunks}: encode {te/5:.3f} ms  decode {td/5:.3f} ms")
+print(f"{os.environ.get('ABL','base')} chunks={n_chunks} pad={PAD} slot={enc.stride}: encode {te/5:.3f} ms  decode {td/5:.3f} ms")
