@@ -92,11 +92,10 @@ template <bool CHECK_SYM, int MSH_T>
 __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, char *lds, const char *tab,
                                             u32 msh_rt) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
-    Entries4 cur, nxt;
-    cur.load(wv[0], tab);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        if (d < 3) nxt.load(wv[d + 1], tab);
+        Entries4 cur;
+        cur.load(wv[d], tab);
         if (CHECK_SYM) {
             const u32 w = wv[d];
             bad = max(max(bad, max((w << 4) & 0xFF0u, (w >> 4) & 0xFF0u)), max((w >> 12) & 0xFF0u, (w >> 20) & 0xFF0u));
@@ -108,7 +107,6 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u3
         const EncSym s2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt);
         const EncSym s3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt);
         o.put(lds, (s3.bits << s2.k) | s2.bits, s2.k + s3.k);
-        if (d < 3) cur = nxt;
     }
 }
 
