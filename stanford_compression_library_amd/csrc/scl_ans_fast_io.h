@@ -8,8 +8,8 @@
 //   stream out : completed big-endian words go to a per-lane ring in LDS (word w of thread t at [w][t]: bank =
 //                t mod 32 for every w, so the scattered ds_write_b32 never conflict) and leave as 64 contiguous
 //                bytes (4 back-to-back 16-byte stores) once 16 words are pending (AnsBackWriter);
-//   stream in  : 64-byte blocks (one prefetched in registers), byte-swapped once into the same kind of ring; the
-//                64-bit bit window refills one word at a time from it (AnsBitReader).
+//   stream in  : whole 128-byte lines prefetched into registers, byte-swapped and moved into the same kind of ring
+//                one 64-byte half at a time; the 64-bit bit window refills one word at a time from it (AnsBitReader).
 // The ring of a workgroup must start at LDS offset 0 (addresses wrap with a single AND).
 #pragma once
 #include "scl_common.h"
@@ -141,8 +141,9 @@ struct AnsBitReader {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
     const uint4 *base;
     u64 n_blocks16;  // readable 16-byte blocks
-    u64 next64;      // index of the next 64-byte block to prefetch
-    uint4 pf[4];     // prefetched block, next to enter the ring
+    u64 next_line;   // index of the next 128-byte line to prefetch
+    uint4 pf[8];     // prefetched line: its two 64-byte halves enter the ring one at a time
+    u32 stage;       // 0: the lower half of pf is next, 1: the upper half
     u32 ra;          // LDS byte address of the next ring word to read (thread column, wraps inside the ring)
     u32 wa;          // LDS byte address of the ring half that is filled next
     u32 nrd, nwr;    // words read from / written to the ring
@@ -150,21 +151,23 @@ struct AnsBitReader {
     int sh;          // lookahead = low32((A:B) >> sh); sh in [0,31]
     u32 bias;        // consumed bits = 32*nrd - sh - bias
 
-    __device__ __forceinline__ void load64(u64 j) {
+    __device__ __forceinline__ void load_line(u64 j) {  // whole 128-byte line: one HBM burst instead of two
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u64 idx = j * 4 + i;
+        for (int i = 0; i < 8; ++i) {
+            const u64 idx = j * 8 + i;
             pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
         }
     }
-    __device__ __forceinline__ void push_pf(char *lds) {
+    __device__ __forceinline__ void push_half(char *lds, const uint4 &q0, const uint4 &q1, const uint4 &q2,
+                                              const uint4 &q3) {
         char *r = lds + wa;
+        const uint4 blk[4] = {q0, q1, q2, q3};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32 *>(r + (4 * i + 0) * THREADS * 4) = __builtin_bswap32(pf[i].x);
-            *reinterpret_cast<u32 *>(r + (4 * i + 1) * THREADS * 4) = __builtin_bswap32(pf[i].y);
-            *reinterpret_cast<u32 *>(r + (4 * i + 2) * THREADS * 4) = __builtin_bswap32(pf[i].z);
-            *reinterpret_cast<u32 *>(r + (4 * i + 3) * THREADS * 4) = __builtin_bswap32(pf[i].w);
+            *reinterpret_cast<u32 *>(r + (4 * i + 0) * THREADS * 4) = __builtin_bswap32(blk[i].x);
+            *reinterpret_cast<u32 *>(r + (4 * i + 1) * THREADS * 4) = __builtin_bswap32(blk[i].y);
+            *reinterpret_cast<u32 *>(r + (4 * i + 2) * THREADS * 4) = __builtin_bswap32(blk[i].z);
+            *reinterpret_cast<u32 *>(r + (4 * i + 3) * THREADS * 4) = __builtin_bswap32(blk[i].w);
         }
         wa ^= 16 * THREADS * 4;
         nwr += 16;
@@ -178,23 +181,29 @@ struct AnsBitReader {
     // call at least every 16 symbols (<= 6 words consumed in between)
     __device__ __forceinline__ void maybe_refill(char *lds) {
         if (nwr - nrd <= 16) {
-            push_pf(lds);
-            load64(next64++);
+            if (stage == 0) {
+                push_half(lds, pf[0], pf[1], pf[2], pf[3]);
+                stage = 1;
+            } else {
+                push_half(lds, pf[4], pf[5], pf[6], pf[7]);
+                stage = 0;
+                load_line(next_line++);
+            }
         }
     }
     __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid) {
         base = reinterpret_cast<const uint4 *>(in);
         n_blocks16 = in_size_bytes >> 4;
-        const u64 j0 = bit_off >> 9;
+        const u64 j0 = bit_off >> 10;
         wa = tid * 4;
         nwr = 0;
-        load64(j0);
-        push_pf(lds);
-        load64(j0 + 1);
-        push_pf(lds);
-        load64(j0 + 2);
-        next64 = j0 + 3;
-        const u32 w0 = (u32)(bit_off >> 5) & 15u;
+        load_line(j0);
+        push_half(lds, pf[0], pf[1], pf[2], pf[3]);
+        push_half(lds, pf[4], pf[5], pf[6], pf[7]);
+        load_line(j0 + 1);
+        next_line = j0 + 2;
+        stage = 0;
+        const u32 w0 = (u32)(bit_off >> 5) & 31u;
         ra = tid * 4 + w0 * THREADS * 4;
         nrd = w0;
         const u32 pos = (u32)bit_off & 31u;
