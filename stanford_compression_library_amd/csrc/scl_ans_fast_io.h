@@ -206,6 +206,9 @@ struct AnsBitReader {
         const u32 w0 = (u32)(bit_off >> 5) & 31u;
         ra = tid * 4 + w0 * THREADS * 4;
         nrd = w0;
+        // a stream that starts in the upper half of its line has fewer than 17 words ahead of it: top the ring
+        // up before the first word is read (the lower half of the ring is already behind the read position)
+        maybe_refill(lds);
         const u32 pos = (u32)bit_off & 31u;
         const u32 first = next_word(lds);
         if (pos == 0) {

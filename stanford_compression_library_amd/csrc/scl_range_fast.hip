@@ -34,10 +34,14 @@ struct RgOut {
     u32 overflow;
     u64 cap;   // slot capacity in bytes
     u8 *slot;
+    uint4 held[4];  // first 64-byte half of the current line (stored together with the second half)
+    u32 have_held;
 
     __device__ __forceinline__ void init(u32 tid, u8 *slot_, u64 cap_) {
         overflow = 0;
         cap = cap_;
+        have_held = 0;
+        held[0] = held[1] = held[2] = held[3] = make_uint4(0, 0, 0, 0);
         acc = 0;
         cnt = 0;
         ra = fa = tid * 4;
@@ -64,14 +68,29 @@ struct RgOut {
             u32 w[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * RGE_THREADS * 4);
-            if (4 * (u64)nfl + 64 <= cap) {
-                uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)nfl);
-                p[0] = make_uint4(w[0], w[1], w[2], w[3]);
-                p[1] = make_uint4(w[4], w[5], w[6], w[7]);
-                p[2] = make_uint4(w[8], w[9], w[10], w[11]);
-                p[3] = make_uint4(w[12], w[13], w[14], w[15]);
+            const uint4 q0 = make_uint4(w[0], w[1], w[2], w[3]), q1 = make_uint4(w[4], w[5], w[6], w[7]);
+            const uint4 q2 = make_uint4(w[8], w[9], w[10], w[11]), q3 = make_uint4(w[12], w[13], w[14], w[15]);
+            if (have_held) {  // second half of a line: store the whole 128 bytes at once
+                if (4 * (u64)nfl + 64 <= cap) {
+                    uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+                    p[0] = held[0];
+                    p[1] = held[1];
+                    p[2] = held[2];
+                    p[3] = held[3];
+                    p[4] = q0;
+                    p[5] = q1;
+                    p[6] = q2;
+                    p[7] = q3;
+                } else {
+                    overflow = 1;
+                }
+                have_held = 0;
             } else {
-                overflow = 1;
+                held[0] = q0;
+                held[1] = q1;
+                held[2] = q2;
+                held[3] = q3;
+                have_held = 1;
             }
             nfl += 16;
             pend -= 16;
@@ -85,6 +104,13 @@ struct RgOut {
         if (words * 4 + cnt > cap) {
             overflow = 1;
             return words * 4 + cnt;
+        }
+        if (have_held) {  // counted in nfl already: bytes [4*(nfl-16), 4*nfl)
+            uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+            p[0] = held[0];
+            p[1] = held[1];
+            p[2] = held[2];
+            p[3] = held[3];
         }
         u32 a = fa;
         for (u32 j = 0; j < pend; ++j) {
@@ -392,12 +418,12 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     const u32 m_log2 = P.m_log2, slot_max = M - 1;
 
     u32 i = 0;
-    // 64 symbols per iteration: four registers, one burst of four 16-byte stores
+    // 128 symbols per iteration: eight registers, one burst of eight 16-byte stores (a whole line)
 #pragma nounroll
-    for (; i + 64 <= n; i += 64) {
-        uint4 a[4];
+    for (; i + 128 <= n; i += 128) {
+        uint4 a[8];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 8; ++b) {
             u32 ow[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -415,7 +441,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         }
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) p[b] = a[b];
+        for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     for (; i < n; ++i) {  // ragged tail
         dst[i] = (u8)rg_decode_symbol(low, range, state, r, lds, tab, s2s, m_log2, slot_max);

@@ -196,20 +196,20 @@ __global__ void __launch_bounds__(TF_THREADS) tans_decode_fast_kernel(TansFastDe
         dst[--i] = (u8)e;
         if ((i & 3u) == 0) r.maybe_refill(lds);
     }
-    while (i & 63u) {
+    while (i & 127u) {
         const uint4 v = tf_decode16(x, r, lds, tab, idx_mask, cb);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
 #pragma nounroll
-    while (i) {
-        uint4 a[4];
+    while (i) {  // one full 128-byte line per iteration
+        uint4 a[8];
 #pragma unroll
-        for (int b = 3; b >= 0; --b) a[b] = tf_decode16(x, r, lds, tab, idx_mask, cb);
-        i -= 64;
+        for (int b = 7; b >= 0; --b) a[b] = tf_decode16(x, r, lds, tab, idx_mask, cb);
+        i -= 128;
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) p[b] = a[b];
+        for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     const u32 used_bits = r.consumed();
     if (used_bits > avail) st |= SCL_ST_TRUNCATED;
