@@ -45,10 +45,21 @@ struct AnsBackWriter {
     static __device__ __forceinline__ u32 *ring_at(char *lds, u32 byte_addr) {
         return reinterpret_cast<u32 *>(lds + byte_addr);
     }
-    // append `w` bits (v < 2^w, w <= 24 unless the accumulator is known to hold < 8 bits) in front of the stream
+    // append `w` bits (v < 2^w, w < 32) in front of the stream
     __device__ __forceinline__ void put(char *lds, u32 v, u32 w) {
         const u32 lo2 = (v << nacc) | lo;
         const u32 nacc2 = nacc + w;
+#if SCL_BRANCHFREE_PUT
+        // branch-free: the current word is always written to its ring slot (an incomplete word is simply written
+        // again later); whether the slot advances is arithmetic on the carry out of the 5-bit bit counter
+        *ring_at(lds, ra) = __builtin_bswap32(lo2);
+        const u32 m = 0u - (nacc2 >> 5);                 // all ones iff the word completed (nacc2 < 64)
+        ra = (ra + (m & (THREADS * 4))) & (RING_BYTES - 1);
+        pend -= m;
+        const u32 hi = v >> ((32 - nacc) & 31);          // only used when m != 0, which implies nacc >= 1
+        lo = (hi & m) | (lo2 & ~m);
+        nacc = nacc2 & 31;
+#else
         if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
             *ring_at(lds, ra) = __builtin_bswap32(lo2);
             ra = (ra + THREADS * 4) & (RING_BYTES - 1);
@@ -59,6 +70,7 @@ struct AnsBackWriter {
             lo = lo2;
             nacc = nacc2;
         }
+#endif
     }
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
         if (w > 16) {
