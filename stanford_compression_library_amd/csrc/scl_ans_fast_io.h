@@ -20,7 +20,7 @@
 // compares, carries, left shifts, SDWA, every VOP3 form, the multiplies and any SGPR operand cost twice that.
 // Hence: sign-bit arithmetic instead of compare+carry, model constants as template literals, fields laid out
 // so they need no extraction (k1 rides in the byte v_mad_u32_u24 ignores).
-template <int THREADS>
+template <int THREADS, bool HOLD_HALF_LINE = true>
 struct AnsBackWriter {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
     u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
@@ -96,7 +96,13 @@ struct AnsBackWriter {
             // memory order is the reverse of completion order: word j of this group sits at -4*(nfl + j + 1)
             const uint4 q0 = make_uint4(w[15], w[14], w[13], w[12]), q1 = make_uint4(w[11], w[10], w[9], w[8]);
             const uint4 q2 = make_uint4(w[7], w[6], w[5], w[4]), q3 = make_uint4(w[3], w[2], w[1], w[0]);
-            if (have_held) {  // this group is the lower-address half of the line whose upper half is held
+            if (!HOLD_HALF_LINE) {  // register-starved callers: plain 64-byte bursts
+                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
+                p[0] = q0;
+                p[1] = q1;
+                p[2] = q2;
+                p[3] = q3;
+            } else if (have_held) {  // this group is the lower-address half of the line whose upper half is held
                 uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
                 p[0] = q0;
                 p[1] = q1;

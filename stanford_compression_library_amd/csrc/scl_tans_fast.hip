@@ -15,7 +15,7 @@
 
 #define TF_THREADS 1024
 #define TF_RING_BYTES (32 * TF_THREADS * 4)
-typedef AnsBackWriter<TF_THREADS> TfOut;
+typedef AnsBackWriter<TF_THREADS, false> TfOut;  // 1024 lanes per workgroup leave 128 VGPRs: no room to hold half a line
 typedef AnsBitReader<TF_THREADS> TfIn;
 
 struct TfSym {
@@ -73,26 +73,30 @@ __global__ void __launch_bounds__(TF_THREADS) tans_encode_fast_kernel(TansFastDe
     o.init(threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L, bad = 0;
 
-    const u32 n_lines = n >> 7;
+    // 1024 lanes per workgroup leave 128 VGPRs per lane, so the input is staged as 64-byte half lines (two
+    // 16-register buffers) instead of the whole lines of the rANS encoder
+    const u32 n_lines = n >> 6;  // 64-byte units
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-    Line128 cur, nxt;
-    if (n_lines) cur.load(src16);
+    uint4 cur[4], nxt[4];
+    if (n_lines) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = src16[i];
+    }
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
-        if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));
-#pragma nounroll
-        for (int half = 0; half < 2; ++half) {
+        if (t + 1 < n_lines) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tf_encode16(cur.v[i], x, o, bad, lds, sym_tab);
-                if (i & 1) o.maybe_flush(lds);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
+            for (int i = 0; i < 4; ++i) nxt[i] = src16[4 * (t + 1) + i];
         }
-        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tf_encode16(cur[i], x, o, bad, lds, sym_tab);
+            if (i & 1) o.maybe_flush(lds);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
     }
-    u32 i = n_lines << 7;
+    u32 i = n_lines << 6;
     for (; i + 16 <= n; i += 16) {
         tf_encode16(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, lds, sym_tab);
         o.maybe_flush(lds);
