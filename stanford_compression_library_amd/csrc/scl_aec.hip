@@ -45,21 +45,43 @@ struct scl_aec_model {
     u32 *d_freq, *d_cum;
 };
 
-// Per-lane frequency model (one of the three kinds); `row` points at the K counts of the current context.
+// Per-lane frequency model (one of the three kinds); the coders only see counts through rd()/wr().
+// LDS16 = true: the adaptive counts of this lane live in LDS as u16 (cell c of thread t at [c][t], so a wave's
+// accesses spread over all banks whatever cells the lanes touch) -- "per-lane context tables in LDS",
+// BASELINE.json configs[3].  Used when K^(k+1) <= 256 cells and the counts cannot exceed 16 bits.
+// LDS16 = false: counts are u32 in caller-provided global scratch (any K, k).
+#define AEC_LDS_CELLS 256
+template <bool LDS16>
 struct LaneModel {
     const AecDev *P;
-    u32 *cnt;   // private scratch (IID / ORDERK)
-    u64 ctx;    // ORDERK: flattened index of the last k symbol indices (starts at 0, :116)
-    u32 bad;    // rescale branch of the order-k model reached (raises AxisError in the reference)
+    u32 *cnt;    // private global scratch (IID / ORDERK): ORDERK stores count - 1 (zero-filled by the host)
+    u16 *lcnt;   // this thread's column of the LDS table: actual counts
+    u64 ctx;     // ORDERK: flattened index of the last k symbol indices (starts at 0, :116)
+    u32 bad;     // rescale branch of the order-k model reached (raises AxisError in the reference)
 
-    __device__ __forceinline__ void init(const AecDev *P_, u32 *scratch, u64 chunk) {
+    __device__ __forceinline__ u32 rd(u64 cell) const {
+        if (LDS16) return lcnt[cell * 256];
+        return cnt[cell] + ((P->kind == SCL_MODEL_ORDERK) ? 1u : 0u);
+    }
+    __device__ __forceinline__ void wr(u64 cell, u32 v) {
+        if (LDS16)
+            lcnt[cell * 256] = (u16)v;
+        else
+            cnt[cell] = v - ((P->kind == SCL_MODEL_ORDERK) ? 1u : 0u);
+    }
+    __device__ __forceinline__ void init(const AecDev *P_, u32 *scratch, u64 chunk, u16 *lds_col) {
         P = P_;
         ctx = 0;
         bad = 0;
-        cnt = scratch ? scratch + chunk * P_->cells : nullptr;
-        if (P->kind == SCL_MODEL_IID)
+        lcnt = lds_col;
+        cnt = (!LDS16 && scratch) ? scratch + chunk * P_->cells : nullptr;
+        if (LDS16) {
+            for (u64 j = 0; j < P->cells; ++j) lcnt[j * 256] = (u16)((P->kind == SCL_MODEL_IID) ? P->d_freq[j] : 1u);
+        } else if (P->kind == SCL_MODEL_IID) {
             for (u32 j = 0; j < P->K; ++j) cnt[j] = P->d_freq[j];
+        }
     }
+    __device__ __forceinline__ u64 row_base() const { return (P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0; }
     // cumulative count below s, frequency of s and total of the current distribution (freqs_current)
     __device__ __forceinline__ void lookup(u32 s, const u32 *s_f, const u32 *s_c, u64 &c, u64 &f, u64 &T) const {
         if (P->kind == SCL_MODEL_FIXED) {
@@ -68,11 +90,10 @@ struct LaneModel {
             T = P->total0;
             return;
         }
-        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
-        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        const u64 rb = row_base();
         u64 acc = 0, cs = 0, fs = 0;
         for (u32 j = 0; j < P->K; ++j) {
-            const u64 v = (u64)row[j] + add;
+            const u64 v = rd(rb + j);
             if (j == s) {
                 cs = acc;
                 fs = v;
@@ -85,10 +106,9 @@ struct LaneModel {
     }
     __device__ __forceinline__ u64 total(const u32 *) const {
         if (P->kind == SCL_MODEL_FIXED) return P->total0;
-        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
-        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        const u64 rb = row_base();
         u64 acc = 0;
-        for (u32 j = 0; j < P->K; ++j) acc += (u64)row[j] + add;
+        for (u32 j = 0; j < P->K; ++j) acc += rd(rb + j);
         return acc;
     }
     // largest s with cum[s] <= cmax; returns s and its (c, f)
@@ -106,41 +126,41 @@ struct LaneModel {
             f = s_f[lo];
             return lo;
         }
-        const u32 add = (P->kind == SCL_MODEL_ORDERK) ? 1u : 0u;
-        const u32 *row = cnt + ((P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0);
+        const u64 rb = row_base();
         u64 acc = 0;
         u32 j = 0;
         for (; j + 1 < P->K; ++j) {
-            const u64 v = (u64)row[j] + add;
+            const u64 v = rd(rb + j);
             if (acc + v > cmax) break;
             acc += v;
         }
         c = acc;
-        f = (u64)row[j] + add;
+        f = rd(rb + j);
         return j;
     }
     __device__ __forceinline__ void update(u32 s) {
         if (P->kind == SCL_MODEL_FIXED) return;
         if (P->kind == SCL_MODEL_IID) {  // probability_models.py:83-92
-            cnt[s] += 1;
+            wr(s, rd(s) + 1);
             u64 tot = 0;
-            for (u32 j = 0; j < P->K; ++j) tot += cnt[j];
+            for (u32 j = 0; j < P->K; ++j) tot += rd(j);
             if (tot >= P->max_total)
                 for (u32 j = 0; j < P->K; ++j) {
-                    const u32 h = cnt[j] >> 1;
-                    cnt[j] = h > 1 ? h : 1;
+                    const u32 h = rd(j) >> 1;
+                    wr(j, h > 1 ? h : 1);
                 }
             return;
         }
         // order-k, probability_models.py:143-160
         const u64 cell = ctx * P->K + s;
-        const u32 v = cnt[cell] + 1;  // stored value is count - 1
-        cnt[cell] = v;
+        const u32 v = rd(cell) + 1;
+        wr(cell, v);
         if (P->k > 0) ctx = (ctx * P->K + s) % P->ctx_mod;  // past_k[1:] + [s]
-        if ((u64)v + 1 >= P->max_total) bad = 1;  // np.max(scalar, 1) -> AxisError in the reference
+        if ((u64)v >= P->max_total) bad = 1;  // np.max(scalar, 1) -> AxisError in the reference
     }
 };
 
+template <bool LDS16>
 __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__restrict__ sym, u64 sym_stride,
                                                         const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                         u8 *__restrict__ out, u64 out_stride,
@@ -148,6 +168,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
                                                         u32 *__restrict__ status, u32 *__restrict__ scratch) {
     __shared__ u32 s_f[256];
     __shared__ u32 s_c[256];
+    __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
     if (P.kind == SCL_MODEL_FIXED) {
         scl_load_table(s_f, P.d_freq, P.K);
         scl_load_table(s_c, P.d_cum, P.K);
@@ -158,8 +179,8 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
     const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
-    LaneModel mdl;
-    mdl.init(&P, scratch, c);
+    LaneModel<LDS16> mdl;
+    mdl.init(&P, scratch, c, s_cnt + threadIdx.x);
     FwdBitWriter w;
     w.init(out + c * out_stride, out_stride);
     u32 st = 0;
@@ -218,6 +239,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     if (status) status[c] = st;
 }
 
+template <bool LDS16>
 __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                                                         const u64 *__restrict__ bit_off,
                                                         const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -226,6 +248,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
                                                         u32 *__restrict__ status, u32 *__restrict__ scratch) {
     __shared__ u32 s_f[256];
     __shared__ u32 s_c[256];
+    __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
     if (P.kind == SCL_MODEL_FIXED) {
         scl_load_table(s_f, P.d_freq, P.K);
         scl_load_table(s_c, P.d_cum, P.K);
@@ -252,8 +275,8 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
         if (status) status[c] = st;
         return;
     }
-    LaneModel mdl;
-    mdl.init(&P, scratch, c);
+    LaneModel<LDS16> mdl;
+    mdl.init(&P, scratch, c, s_cnt + threadIdx.x);
     u8 *dst = out_sym + c * out_stride;
     // bit positions relative to the first bit after the header; bits past the end read as 0 (:258-261)
     const u64 body = r.pos;
@@ -408,6 +431,14 @@ extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chu
     return scl_round_up(m->dev.cells * n_chunks * sizeof(u32), 256);
 }
 
+// per-lane context tables in LDS: at most 256 cells, counts (initial + one per symbol) must fit 16 bits
+static bool aec_use_lds(const scl_aec_model *m, u64 max_symbols) {
+    if (m->dev.kind == SCL_MODEL_FIXED || m->dev.cells == 0 || m->dev.cells > AEC_LDS_CELLS) return false;
+    u64 max_init = 1;
+    if (m->dev.kind == SCL_MODEL_IID) max_init = m->dev.total0;  // bound on any single initial count
+    return max_init + max_symbols < 65535 && m->dev.max_total > max_init + max_symbols;
+}
+
 static int aec_prepare_scratch(const scl_aec_model *m, u64 n_chunks, void *d_scratch, u64 scratch_bytes,
                                hipStream_t st) {
     const u64 need = m->dev.cells * n_chunks * sizeof(u32);
@@ -427,13 +458,20 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "aec_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
-    if (rc) return rc;
+    if (!aec_use_lds(m, chunk_len)) {
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+        if (rc) return rc;
+    }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    hipLaunchKernelGGL(aec_encode_kernel, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride, d_lens,
-                       chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
-                       (u32 *)d_scratch);
+    if (aec_use_lds(m, chunk_len))
+        hipLaunchKernelGGL(aec_encode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
+                           (u32 *)d_scratch);
+    else
+        hipLaunchKernelGGL(aec_encode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
+                           (u32 *)d_scratch);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -448,13 +486,20 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
-    if (rc) return rc;
+    if (!aec_use_lds(m, out_cap)) {
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+        if (rc) return rc;
+    }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    hipLaunchKernelGGL(aec_decode_kernel, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
-                       d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
-                       d_status, (u32 *)d_scratch);
+    if (aec_use_lds(m, out_cap))
+        hipLaunchKernelGGL(aec_decode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status, (u32 *)d_scratch);
+    else
+        hipLaunchKernelGGL(aec_decode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status, (u32 *)d_scratch);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
