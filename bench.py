@@ -228,6 +228,11 @@ def main():
         total_bytes = in_bytes * world
         value = total_bytes * args.steps / elapsed / 1e6
         traffic = load_traffic_note()
+        # the PMC passes were taken on one workload only: never attach them to another one
+        w = (traffic or {}).get("workload", {})
+        if not (w.get("coder") == args.coder and w.get("table") == args.table and w.get("chunks") == args.chunks
+                and w.get("chunk_len") == args.chunk_len):
+            traffic = None
 
         def roof(ms, name):
             gbs = alg_bytes / (ms * 1e-3) / 1e9

@@ -43,6 +43,10 @@
  *   - per-chunk status words (d_status): 0 = ok, else a bit mask of SCL_ST_*.
  *   - all buffers holding streams must be 16-byte aligned, strides multiples of 16 bytes, and the
  *     input buffer of a decoder must stay readable for 16 bytes past the last stream byte.
+ *     scl_*_slot_bytes returns multiples of 128: with 128-byte aligned base pointers (any hipMalloc /
+ *     torch allocation) every lane then moves whole, aligned 128-byte lines, which is what the tuned
+ *     kernels are built around (smaller alignments are accepted and served by the generic kernels or at
+ *     reduced speed).
  */
 #ifndef SCL_HIP_H
 #define SCL_HIP_H

@@ -19,6 +19,7 @@ for k, v in vals.items():
         out[k] = int(v["FETCH_SIZE"] * 1024 * mult + v["WRITE_SIZE"] * 1024)
         out[k + "_detail"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"], "fetch_multiplier": mult,
                               "read_bytes": int(v["FETCH_SIZE"] * 1024 * mult), "write_bytes": int(v["WRITE_SIZE"] * 1024)}
+out["workload"] = {"coder": "rans", "table": "t256", "chunks": 262144, "chunk_len": 4096}
 out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch, 1 GiB T256 batch"
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out))
