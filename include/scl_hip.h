@@ -177,6 +177,10 @@ void scl_aec_model_destroy(scl_aec_model *m);
 uint64_t scl_aec_slot_bytes(const scl_aec_model *m, uint64_t n_symbols);
 /* bytes of device scratch the adaptive models need for n_chunks concurrent coders (0 for FIXED) */
 uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chunks);
+/* 1 if batches whose chunks hold at most max_symbols symbols are served by the per-lane-LDS-table kernels
+   (adaptive models, alphabet <= 16, <= 16 contexts; needs 16-byte aligned rows and slots of
+   scl_aec_slot_bytes) -- the kernels BASELINE.json configs[3] names; 0 if the generic kernels serve them. */
+int scl_aec_fast_path(const scl_aec_model *m, uint64_t max_symbols);
 int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym, uint64_t sym_stride,
                          const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
                          uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "scl_aec_model_destroy": (None, [_vp]),
     "scl_aec_slot_bytes": (_u64, [_vp, _u64]),
     "scl_aec_scratch_bytes": (_u64, [_vp, _u64]),
+    "scl_aec_fast_path": (_int, [_vp, _u64]),
     "scl_aec_encode_batch": (_int, _ENC_BATCH[:-1] + [_vp, _u64, _vp]),
     "scl_aec_decode_batch": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _vp]),
     "scl_aec_encode_host": (_int, _ENC_HOST),

@@ -237,6 +237,10 @@ class AecModel(_DeviceModel):
         _lib.check(rc, "scl_aec_model_create")
         self.size_bits = int(size_bits)
 
+    def fast_path(self, max_symbols: int) -> bool:
+        """True if chunks of up to max_symbols symbols run on the per-lane-LDS-table kernels (scl_aec_fast.hip)."""
+        return bool(self._L.scl_aec_fast_path(self._h, int(max_symbols)))
+
 
 def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     """Dense (or EncodedBlockWriter-framed) concatenation of a batch: -> (bytes tensor, int64 offsets[n+1])."""

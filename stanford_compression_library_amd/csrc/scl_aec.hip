@@ -26,24 +26,7 @@
 //            probability_models.py:110) with one hipMemsetAsync before the launch.
 #include <string.h>
 
-#include "scl_common.h"
-
-struct AecDev {
-    int kind;
-    u32 K, k;
-    u32 P, size_bits;
-    u64 max_total;
-    u64 cells;  // per-chunk scratch cells (u32)
-    u64 ctx_mod;  // K^k
-    const u32 *d_freq;  // [K] initial frequencies (FIXED / IID)
-    const u32 *d_cum;   // [K] exclusive cumulative of d_freq (FIXED)
-    u32 total0;         // sum of initial frequencies
-};
-
-struct scl_aec_model {
-    AecDev dev;
-    u32 *d_freq, *d_cum;
-};
+#include "scl_aec_internal.h"
 
 // Per-lane frequency model (one of the three kinds); the coders only see counts through rd()/wr().
 // LDS16 = true: the adaptive counts of this lane live in LDS as u16 (cell c of thread t at [c][t], so a wave's
@@ -396,6 +379,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
         m->dev.cells = (model_kind == SCL_MODEL_IID) ? K : 0;
     }
     m->dev.total0 = (u32)tot;
+    ::memcpy(m->h_freq, freq, K * sizeof(u32));
     hipError_t e = hipMalloc((void **)&m->d_freq, 256 * sizeof(u32));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, freq, K * sizeof(u32), hipMemcpyHostToDevice);
@@ -431,6 +415,10 @@ extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chu
     return scl_round_up(m->dev.cells * n_chunks * sizeof(u32), 256);
 }
 
+extern "C" int scl_aec_fast_path(const scl_aec_model *m, uint64_t max_symbols) {
+    return (m && aec_fast_ok(m, max_symbols)) ? 1 : 0;
+}
+
 // per-lane context tables in LDS: at most 256 cells, counts (initial + one per symbol) must fit 16 bits
 static bool aec_use_lds(const scl_aec_model *m, u64 max_symbols) {
     if (m->dev.kind == SCL_MODEL_FIXED || m->dev.cells == 0 || m->dev.cells > AEC_LDS_CELLS) return false;
@@ -458,6 +446,15 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "aec_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
+    // small-alphabet adaptive models: cumulative context rows in LDS, closed-form renormalisation (scl_aec_fast.hip)
+    if (aec_fast_ok(m, chunk_len) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+        sym_stride >= scl_round_up(chunk_len, 16) && (out_stride & 63) == 0 &&
+        out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
+        aec_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                               d_out_nbits, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     if (!aec_use_lds(m, chunk_len)) {
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
         if (rc) return rc;
@@ -486,6 +483,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (aec_fast_ok(m, out_cap) && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
+        (out_stride & 15) == 0 && out_stride >= scl_round_up(out_cap, 16)) {
+        aec_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                               out_cap, d_out_lens, d_consumed, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     if (!aec_use_lds(m, out_cap)) {
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
         if (rc) return rc;

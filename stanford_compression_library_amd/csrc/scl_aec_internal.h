@@ -1,0 +1,31 @@
+// scl_aec_internal.h -- model handle of the arithmetic coder, shared by scl_aec.hip (any parameters) and
+// scl_aec_fast.hip (small-alphabet adaptive models with per-lane context tables in LDS).  Internal to csrc/.
+#pragma once
+#include "scl_common.h"
+
+struct AecDev {
+    int kind;
+    u32 K, k;
+    u32 P, size_bits;
+    u64 max_total;
+    u64 cells;  // per-chunk scratch cells (u32)
+    u64 ctx_mod;  // K^k
+    const u32 *d_freq;  // [K] initial frequencies (FIXED / IID)
+    const u32 *d_cum;   // [K] exclusive cumulative of d_freq (FIXED)
+    u32 total0;         // sum of initial frequencies
+};
+
+struct scl_aec_model {
+    AecDev dev;
+    u32 *d_freq, *d_cum;
+    u32 h_freq[256];  // host copy of the initial frequencies (all ones for ORDERK)
+};
+
+// scl_aec_fast.hip
+bool aec_fast_ok(const scl_aec_model *m, u64 max_symbols);
+void aec_fast_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
+                            u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
+                            u32 *d_status, hipStream_t st);
+void aec_fast_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
+                            const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                            u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);

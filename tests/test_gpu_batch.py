@@ -127,6 +127,108 @@ def test_batch_aec_orderk_vs_oracle(K, k, dev):
     assert np.array_equal(dec.cpu().numpy(), sym) and np.array_equal(used.cpu().numpy(), nbits)
 
 
+AEC_FAST_CASES = [("orderk", 16, 1), ("orderk", 4, 1), ("orderk", 2, 1), ("orderk", 3, 2), ("orderk", 2, 3),
+                  ("orderk", 5, 0), ("orderk", 16, 0), ("orderk", 7, 1), ("iid", 2, 0), ("iid", 11, 0), ("iid", 16, 0)]
+
+
+@pytest.mark.parametrize("kind,K,k", AEC_FAST_CASES)
+def test_batch_aec_lds_table_kernels_vs_oracle(kind, K, k, dev):
+    """scl_aec_fast.hip (configs[3]: per-lane context tables in LDS, closed-form renormalisation, binary64
+    division): 300 ragged chunks (two workgroups), every stream equal to the oracle's; decode from the slots and
+    from a bit-adjacent buffer with garbage after every stream.  Power-of-two alphabets start every chunk on the
+    reference's strict-comparison corner (low == HALF / QTR exactly), i.e. on the literal-loop fallback."""
+    rng = np.random.default_rng(1000 + 17 * K + k)
+    cap = 1024
+    lens = np.concatenate([[0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1023, 1024, 1000],
+                           rng.integers(0, cap + 1, 284)]).astype(np.int32)
+    n_chunks = lens.size
+    if kind == "iid":
+        f_init = rng.integers(1, 40, K).astype(np.uint32)
+        model = models.AecModel(1, f_init.tolist(), K, 0, 1 << 30, 32, 32)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_IID, K, f_init=f_init)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_IID, K, f_init=f_init)
+    else:
+        model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=k)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_ORDERK, K, k=k)
+    assert model.fast_path(cap), "this case must be served by the LDS-table kernels"
+    sym = np.stack([bench_data.markov1_host(K, cap, seed=7000 + c) for c in range(n_chunks)])
+    sym[5] = 0          # constant runs: the interval collapses towards low = 0 / high = 2^32
+    sym[6] = K - 1
+    sym[7, ::2] = 0
+    sym[7, 1::2] = K - 1
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    ref = [o_enc(sym[c, :lens[c]]) for c in range(n_chunks)]
+    for c, (rb, rn) in enumerate(ref):
+        assert int(nbits[c]) == rn, f"chunk {c} (n={lens[c]}): {nbits[c]} bits vs oracle {rn}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    for c in range(n_chunks):
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        if lens[c] > 0:
+            # the reference's own count (it can be one short of the stream on 1-symbol blocks whose interval
+            # ends on a power of two -- the oracle, pinned to the reference, is the judge)
+            assert used[c] == o_dec(ref[c][0], ref[c][1])[1], f"chunk {c}"
+    assert np.mean(used[lens > 64] == nbits[lens > 64]) > 0.98  # ... and that is rare
+    # bit-adjacent streams (arbitrary bit offsets), 0..70 garbage bits after each
+    pieces, new_off, new_avail, pos = [], [], [], 0
+    for c, (rb, rn) in enumerate(ref):
+        g = rng.integers(0, 2, int(rng.integers(0, 71))).astype(np.uint8)
+        pieces += [np.unpackbits(rb)[:rn], g]
+        new_off.append(pos)
+        new_avail.append(rn + g.size)
+        pos += rn + g.size
+    packed = np.packbits(np.concatenate(pieces))
+    buf = torch.zeros((packed.size + 47) // 16 * 16, dtype=torch.uint8, device=dev)
+    buf[:packed.size] = torch.from_numpy(packed).to(dev)
+    dec2, dlens2, used2, status2 = model.decode_batch(buf, torch.tensor(new_off, dtype=torch.int64, device=dev),
+                                                      torch.tensor(new_avail, dtype=torch.int32, device=dev), cap)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    used2, dec2 = used2.cpu().numpy(), dec2.cpu().numpy()
+    for c, (rb, rn) in enumerate(ref):
+        if lens[c] == 0:
+            continue  # quirk Q5
+        assert np.array_equal(dec2[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        stream = np.packbits(np.concatenate([pieces[2 * c], pieces[2 * c + 1]]))
+        o_sym, o_used = o_dec(stream, new_avail[c])
+        assert used2[c] == o_used, f"chunk {c}: consumed {used2[c]} vs oracle {o_used} (stream {rn} bits)"
+
+
+def test_batch_aec_lds_table_kernels_short_chunks(dev):
+    """16 384 chunks of 48 symbols: pounds on the start-of-chunk corners (totals 2, 3, 4, ... are where low and
+    high land exactly on HALF / QTR) -- every stream against the oracle."""
+    for K in (2, 4):
+        n_chunks, n = 1 << 14, 48
+        rng = np.random.default_rng(31 + K)
+        sym = rng.integers(0, K, (n_chunks, n), dtype=np.uint8)
+        sym[:4096] = (rng.random((4096, n)) < 0.9).astype(np.uint8) * (K - 1)  # skewed: long E1/E2 runs
+        model = models.AecModel(2, None, K, 1, 1 << 30, 32, 32)
+        assert model.fast_path(n)
+        enc = model.encode_batch(torch.from_numpy(sym).to(dev))
+        dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, n)
+        torch.cuda.synchronize()
+        assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+        assert np.array_equal(dec.cpu().numpy()[:, :n], sym) and np.array_equal(used.cpu().numpy(), enc.nbits.cpu().numpy())
+        nbits = enc.nbits.cpu().numpy()
+        data = enc.data.cpu().numpy()[:n_chunks * enc.stride].reshape(n_chunks, enc.stride)
+        for c in range(n_chunks):
+            rb, rn = orc.aec_encode(sym[c], orc.MODEL_ORDERK, K, k=1)
+            assert int(nbits[c]) == rn, f"K={K} chunk {c}"
+            nb = (rn + 7) // 8
+            got = data[c, :nb].copy()
+            if rn % 8:
+                got[-1] &= (0xFF00 >> (rn % 8)) & 0xFF
+            assert np.array_equal(got, rb), f"K={K} chunk {c}"
+
+
 def _frame_reference(bits):
     """EncodedBlockWriter.write_block on a bit vector (encoded_stream.py:23-46,94-103,150-175), in numpy"""
     n = bits.size
