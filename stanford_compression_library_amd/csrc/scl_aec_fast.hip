@@ -8,13 +8,15 @@
 // alphabet 2..16 and at most 16 contexts (K^k <= 16: order-1 K <= 16, order-2 K <= 4, ...), totals that stay
 // below 2^15 and below the model's rescale threshold for the whole chunk.  Everything else -> scl_aec.hip.
 //
-// What is different from the generic kernel (13.7 / 21.7 ms per 256 MiB, profiles/r01_bench_aec_k16.json):
-//  * Model layout.  A context row is stored as 16 u16 INCLUSIVE cumulative counts E[j] = count[0] + .. + count[j]
-//    (E[15] = total; unused symbols are padded with the total), 32 bytes per row, row `ctx` of thread t at
-//    LDS [ctx][half][t] as two uint4: c = E[s-1], d = E[s], T = E[15] are single 2-byte reads, the update
-//    `count[s] += 1` is E[j] += 1 for j >= s = eight v_pk_add_u16 on the row with a mask row from a 512-byte LUT,
-//    and the decoder's search max{s : c[s] <= target} is a packed compare-and-count over the 8 row registers.
-//    16 contexts x 32 B x 256 lanes = 128 KiB: one workgroup of 256 lanes per CU (one wave per SIMD).
+// What is different from the generic kernel (13.7 / 21.7 ms per 256 MiB of order-1 K = 16 data, now 1.9 / 2.6 ms):
+//  * Model layout.  A context row is 16 u16 EXCLUSIVE cumulative counts X[j] = count[0] + .. + count[j-1]
+//    (entries past the alphabet hold the total), 32 bytes per row, row `ctx` of thread t at LDS [ctx][t], plus a
+//    u32 total per row: c = X[s], d = X[s+1] (or the total) are two 2-byte reads at one address, the update
+//    `count[s] += 1` is X[j] += 1 for j > s = eight v_pk_add_u16 on the row with a mask row from a 512-byte LUT
+//    and one ds_add_u32 on the total, and the decoder's search max{s : c[s] <= target} is a packed
+//    compare-and-count over the 8 row registers.  16 contexts x 32 B x 256 lanes = 128 KiB (+ 16 KiB totals):
+//    one workgroup of 256 lanes per CU, i.e. ONE wave per SIMD -- the kernels are bound by how fast a lone wave
+//    issues instructions (~6 clk each, profiles/r01_ubench_dp_issue.txt), so every instruction counts.
 //  * Arithmetic.  (rng*c)//T and ((state-low+1)*T-1)//rng are evaluated in binary64: every operand is an integer
 //    below 2^47, q = trunc((num + 0.5) * x) with x = 1/den refined by two Newton steps from v_rcp_f32 is exact
 //    because the quotient's error (< 2^-18 resp. 2^-35) is below the distance 0.5/den of (num + 0.5)/den from the
@@ -23,11 +25,11 @@
 //    bits, then m = number of leading (1,0) bit pairs of (low, hm) below them E3 steps.  The reference's STRICT
 //    comparisons (quirk Q1: `high < HALF`, `low > HALF`, `low > QTR and high < 3*QTR`) differ from this only when
 //    low or high hits a power-of-two boundary inside the shifted-out prefix, i.e. when
-//    (low << (k+m+1)) == 0 or (high << (k+m+1)) == 0; those symbols (probability ~2^-20) and runs of more than
-//    32 - k pending bits take the literal loops of the reference.
-//  * Encoder software pipeline: the model reads/updates of symbol i+1 are issued before the arithmetic of
-//    symbol i, so LDS latency is off the critical path; output words collect in a 16-register FIFO and leave as
-//    64-byte bursts; input arrives as 16-byte loads, one block ahead.
+//    ctz(low) + k + m + 1 >= 32 or ctz(high) + k + m + 1 >= 32; those symbols (rare after the first few of a
+//    chunk) and runs of more than 32 - k pending bits take the literal loops of the reference.
+//  * Encoder software pipeline: the model reads of symbol i+1 are in flight while symbol i is coded; words go
+//    straight to the slot (4-byte stores, L2 merges them); symbols arrive four per 32-bit load, one word ahead,
+//    the load unconditional so that it is not waited for at once.
 #include "scl_aec_internal.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -38,12 +40,17 @@ typedef u16 __attribute__((may_alias)) u16_lds;
 typedef u32 __attribute__((may_alias)) u32_lds;
 typedef uint4 __attribute__((may_alias)) uint4_lds;
 
+#ifndef AF_ABLATE
+#define AF_ABLATE 0  // timing experiments only (tools/ablate_aec.sh); 0 = the product
+#endif
 #define AF_THREADS 256
-#define AF_HALF_BYTES (AF_THREADS * 16)  // one 16-byte half row of every thread
-#define AF_CTX_BYTES (2 * AF_HALF_BYTES)
-#define AF_TABLE_BYTES (16 * AF_CTX_BYTES)
+#define AF_CTX_BYTES (AF_THREADS * 32)      // one 32-byte row of every thread
+#define AF_TABLE_BYTES (16 * AF_CTX_BYTES)  // 128 KiB
+#define AF_TOT_BASE AF_TABLE_BYTES          // u32 totals [ctx][thread]
+#define AF_TOT_BYTES (16 * AF_THREADS * 4)
+#define AF_LUT_BASE (AF_TOT_BASE + AF_TOT_BYTES)
 #define AF_LUT_BYTES 512
-#define AF_LDS_BYTES (AF_TABLE_BYTES + AF_LUT_BYTES)
+#define AF_LDS_BYTES (AF_LUT_BASE + AF_LUT_BYTES)
 #define AF_HALF 0x80000000u
 #define AF_QTR 0x40000000u
 
@@ -51,7 +58,8 @@ struct AecFastDev {
     u32 K;          // alphabet size 2..16
     u32 nctx;       // K^k <= 16
     u32 ctx_magic;  // ceil(2^16 / nctx): (v * magic) >> 16 == v / nctx for v < 272
-    u32 initE[8];   // 16 packed u16: inclusive cumulative initial counts, padded with the total
+    u32 total0;     // initial total of a row
+    u32 initX[8];   // 16 packed u16: EXCLUSIVE cumulative initial counts X[j] = sum_{i<j}, padded with the total
 };
 
 __device__ __forceinline__ u32 af_pk_add(u32 a, u32 b) {
@@ -78,115 +86,120 @@ struct AfRow {
     uint4 a, b;
 };
 
+// LDS image of one workgroup: rows (exclusive cumulative counts, 32 bytes per context and thread), row totals,
+// and the update masks LUT[s][j] = (j > s)
 __device__ __forceinline__ void af_setup_tables(char *lds, const AecFastDev &P, u32 tid) {
-    // mask rows: LUT[s] = packed (j >= s) for j = 0..15
     if (tid < 128) {
         const u32 s = tid >> 3, r = tid & 7;  // register r holds elements 2r, 2r+1
-        const u32 v = ((2 * r >= s) ? 1u : 0u) | ((2 * r + 1 >= s) ? 0x10000u : 0u);
-        *reinterpret_cast<u32_lds *>(lds + AF_TABLE_BYTES + s * 32 + r * 4) = v;
+        const u32 v = ((2 * r > s) ? 1u : 0u) | ((2 * r + 1 > s) ? 0x10000u : 0u);
+        *reinterpret_cast<u32_lds *>(lds + AF_LUT_BASE + s * 32 + r * 4) = v;
     }
-    const uint4 a = make_uint4(P.initE[0], P.initE[1], P.initE[2], P.initE[3]);
-    const uint4 b = make_uint4(P.initE[4], P.initE[5], P.initE[6], P.initE[7]);
+    const uint4 a = make_uint4(P.initX[0], P.initX[1], P.initX[2], P.initX[3]);
+    const uint4 b = make_uint4(P.initX[4], P.initX[5], P.initX[6], P.initX[7]);
     for (u32 c = 0; c < P.nctx; ++c) {
-        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 16) = a;
-        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + AF_HALF_BYTES + tid * 16) = b;
+        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32) = a;
+        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32 + 16) = b;
+        *reinterpret_cast<u32_lds *>(lds + AF_TOT_BASE + c * (AF_THREADS * 4) + tid * 4) = P.total0;
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ u32 af_elem_addr(u32 rowbase, u32 j) {  // byte address of E[j] of this thread's row
-    return rowbase + (j >> 3) * AF_HALF_BYTES + (j & 7) * 2;
-}
+template <bool ORDER1>
 __device__ __forceinline__ u32 af_next_ctx(const AecFastDev &P, u32 ctx, u32 s) {  // past_k[1:] + [s], :146-151
+    if (ORDER1) return s;
     const u32 v = ctx * P.K + s;
     return v - ((v * P.ctx_magic) >> 16) * P.nctx;
 }
-__device__ __forceinline__ AfRow af_row_plus_mask(const AfRow &R, const char *lds, u32 s) {
-    const uint4 ia = *reinterpret_cast<const uint4_lds *>(lds + AF_TABLE_BYTES + s * 32);
-    const uint4 ib = *reinterpret_cast<const uint4_lds *>(lds + AF_TABLE_BYTES + s * 32 + 16);
+__device__ __forceinline__ AfRow af_row_load(const char *lds, u32 rowbase) {
+    AfRow R;
+    R.a = *reinterpret_cast<const uint4_lds *>(lds + rowbase);
+    R.b = *reinterpret_cast<const uint4_lds *>(lds + rowbase + 16);
+    return R;
+}
+// update_model with the mask row already loaded
+__device__ __forceinline__ void af_row_store_updated(const AfRow &R, const uint4 &ia, const uint4 &ib, char *lds,
+                                                     u32 rowbase, u32 totaddr) {
+    *reinterpret_cast<uint4_lds *>(lds + rowbase) =
+        make_uint4(af_pk_add(R.a.x, ia.x), af_pk_add(R.a.y, ia.y), af_pk_add(R.a.z, ia.z), af_pk_add(R.a.w, ia.w));
+    *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) =
+        make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
+    __hip_atomic_fetch_add(reinterpret_cast<u32 *>(lds + totaddr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// update_model: count[s] += 1  <=>  X[j] += 1 for j > s, total += 1
+__device__ __forceinline__ AfRow af_row_update(const AfRow &R, char *lds, u32 rowbase, u32 totaddr, u32 s) {
+    const uint4 ia = *reinterpret_cast<const uint4_lds *>(lds + AF_LUT_BASE + s * 32);
+    const uint4 ib = *reinterpret_cast<const uint4_lds *>(lds + AF_LUT_BASE + s * 32 + 16);
     AfRow o;
     o.a = make_uint4(af_pk_add(R.a.x, ia.x), af_pk_add(R.a.y, ia.y), af_pk_add(R.a.z, ia.z), af_pk_add(R.a.w, ia.w));
     o.b = make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
+    *reinterpret_cast<uint4_lds *>(lds + rowbase) = o.a;
+    *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) = o.b;
+    __hip_atomic_fetch_add(reinterpret_cast<u32 *>(lds + totaddr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return o;
 }
 
-// shrink_range (:58-78) on (low, hm = high - 1); c, d = c + f, T from the model
-__device__ __forceinline__ void af_shrink(u32 &low, u32 &hm, u32 c, u32 d, u32 T) {
+// shrink_range (:58-78) on (low, hm = high - 1); c, d = c + f, T from the model, x = 1/T
+__device__ __forceinline__ void af_shrink(u32 &low, u32 &hm, u32 c, u32 d, u32 T, double x) {
     const double rd = (double)(hm - low) + 1.0;
-    const double x = af_recip((double)T);
     const u32 q1 = (u32)(__builtin_fma(rd, (double)c, 0.5) * x);
     const u32 q2 = (u32)(__builtin_fma(rd, (double)d, 0.5) * x);
     hm = (d == T) ? hm : low + q2 - 1;  // (rng*T)//T == rng: high is unchanged (and rng may be 2^32)
     low = low + q1;
 }
 
-// closed-form renormalisation counts; returns true if the literal loops must be used for this symbol
+// closed-form renormalisation counts; returns true if the literal loops must be used for this symbol:
+// ctz(low) + k + m + 1 >= 32 for low != 0, likewise for high (v_ffbl of 0 is -1, which wraps to "no")
 __device__ __forceinline__ bool af_renorm_counts(u32 low, u32 hm, u32 &k, u32 &m) {
     k = (u32)__builtin_clz(low ^ hm);  // low != hm: the interval holds more than one value
     const u32 z = ((low & ~hm) << k) << 1;
     m = (u32)__builtin_clz(~z);
     const u32 sh = k + m + 1;  // <= 32
-    const u32 hi = hm + 1;      // low 32 bits of high
-    const bool lo_edge = (low != 0) & (((low << (sh & 31)) == 0) | (sh >= 32));
-    const bool hi_edge = (hi != 0) & (((hi << (sh & 31)) == 0) | (sh >= 32));
-    return lo_edge | hi_edge;
+    const u32 e_lo = (u32)(__builtin_ffs((int)low) - 1) + sh;
+    const u32 e_hi = (u32)(__builtin_ffs((int)(hm + 1)) - 1) + sh;
+    return max(e_lo, e_hi) >= 32;
 }
 
-// ---- forward bit writer: completed big-endian words collect in a 16-register FIFO, 64-byte bursts ------------
+// ---- forward bit writer: completed big-endian words go straight to the slot (4-byte stores; the stream is a
+// third of the input and L2 merges them -- a register FIFO costs ~50 phi copies per symbol, an LDS ring does not fit)
 struct AfWriter {
     u64 acc;
     u32 nacc;  // < 32 pending bits in acc
-    u32 cnt;   // words in the FIFO
-    u32 w[16];
-    uint4 *dst;
-    u64 nwords;  // words already stored
+    u32 *dst;
+    u32 nwords;
 
     __device__ __forceinline__ void init(u8 *slot) {
         acc = 0;
         nacc = 0;
-        cnt = 0;
         nwords = 0;
-        dst = reinterpret_cast<uint4 *>(slot);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = 0;
-    }
-    __device__ __forceinline__ void push(u32 word) {
-#pragma unroll
-        for (int i = 15; i > 0; --i) w[i] = w[i - 1];
-        w[0] = __builtin_bswap32(word);
-        if (++cnt == 16) {
-            dst[0] = make_uint4(w[15], w[14], w[13], w[12]);
-            dst[1] = make_uint4(w[11], w[10], w[9], w[8]);
-            dst[2] = make_uint4(w[7], w[6], w[5], w[4]);
-            dst[3] = make_uint4(w[3], w[2], w[1], w[0]);
-            dst += 4;
-            nwords += 16;
-            cnt = 0;
-        }
+        dst = reinterpret_cast<u32 *>(slot);
     }
     __device__ __forceinline__ void put(u32 v, u32 nb) {  // v < 2^nb, nb <= 32
         acc = (acc << nb) | v;
         nacc += nb;
         if (nacc >= 32) {
             nacc -= 32;
-            push((u32)(acc >> nacc));
+#if AF_ABLATE == 1
+            nwords++;
+#else
+            dst[nwords++] = __builtin_bswap32((u32)(acc >> nacc));
+#endif
         }
     }
-    __device__ __forceinline__ void put_run(u32 bit, u64 count) {
+    __device__ __forceinline__ void put_run(u32 bit, u32 count) {
         while (count >= 32) {
             put(bit ? 0xFFFFFFFFu : 0u, 32);
             count -= 32;
         }
-        if (count) put(bit ? ((1u << count) - 1u) : 0u, (u32)count);
+        if (count) put(bit ? ((1u << count) - 1u) : 0u, count);
     }
-    __device__ __forceinline__ u64 finish() {  // zero-pads to the next 64-byte boundary
-        const u64 total = (nwords + cnt) * 32 + nacc;
-        if (nacc) put(0, 32 - nacc);
-        while (cnt) push(0);
+    __device__ __forceinline__ u64 finish() {
+        const u64 total = (u64)nwords * 32 + nacc;
+        if (nacc) dst[nwords] = __builtin_bswap32((u32)(acc << (32 - nacc)));
         return total;
     }
 };
 
+template <bool ORDER1>
 __global__ void __launch_bounds__(AF_THREADS)
     aec_fast_encode_kernel(AecFastDev P, const u8 *__restrict__ sym, u64 sym_stride, const u32 *__restrict__ lens,
                            u32 chunk_len, u64 n_chunks, u8 *__restrict__ out, u64 out_stride,
@@ -197,99 +210,115 @@ __global__ void __launch_bounds__(AF_THREADS)
     const u64 chunk = (u64)blockIdx.x * AF_THREADS + tid;
     if (chunk >= n_chunks) return;
     const u32 n = lens ? lens[chunk] : chunk_len;
-    const uint4 *src = reinterpret_cast<const uint4 *>(sym + chunk * sym_stride);
+    const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
     AfWriter wr;
     wr.init(out + chunk * out_stride);
     wr.put(n, 32);
     u32 st = 0;
     u32 low = 0, hm = 0xFFFFFFFFu;
-    u64 pending = 0;
+    u32 pending = 0;  // E3 steps not yet resolved (<= 32 * n < 2^20)
     u32 ctx = 0;
-    uint4 cur = make_uint4(0, 0, 0, 0), pf = make_uint4(0, 0, 0, 0);
-    if (n > 0) pf = src[0];
-    u32 word = 0;
-    u32 c_nx = 0, d_nx = 0, T_nx = 1;
-    for (u32 p = 0; p <= n; ++p) {
-        const u32 cc = c_nx, dd = d_nx, TT = T_nx;
-        if (p < n) {
-            // ---- model access for symbol p (its arithmetic happens in the next iteration) ----
-            if ((p & 15) == 0) {
-                cur = pf;
-                if (p + 16 < n) pf = src[(p >> 4) + 1];
+    u32 nextw = 0;
+    const u32 last_word = n ? (n - 1) >> 2 : 0;
+    u32 c_nx = 0, d_nx = 1, T_nx = 1;
+    double x_nx = 1.0;
+
+    // model stage, split in two so that the arithmetic of the previous symbol runs while the LDS reads are in
+    // flight: model_issue = freqs_current lookup for symbol s (loads only), model_finish = update_model (:118)
+    // and 1/T.  Everything the arithmetic of a symbol needs (c, d, T, 1/T) is ready one iteration ahead.
+    u32 m_rowbase = 0, m_totaddr = 0, m_s = 0, m_draw = 0;
+    AfRow m_R;
+    uint4 m_ia, m_ib;
+    auto model_issue = [&](u32 s) {
+        m_rowbase = ctx * AF_CTX_BYTES + tid * 32;
+        m_totaddr = AF_TOT_BASE + ctx * (AF_THREADS * 4) + tid * 4;
+        m_s = s;
+        const u32 ea = m_rowbase + 2 * s;
+        c_nx = *reinterpret_cast<const u16_lds *>(lds + ea);
+        m_draw = *reinterpret_cast<const u16_lds *>(lds + ea + 2);
+        T_nx = *reinterpret_cast<const u32_lds *>(lds + m_totaddr);
+        m_R = af_row_load(lds, m_rowbase);
+        m_ia = *reinterpret_cast<const uint4_lds *>(lds + AF_LUT_BASE + s * 32);
+        m_ib = *reinterpret_cast<const uint4_lds *>(lds + AF_LUT_BASE + s * 32 + 16);
+        ctx = af_next_ctx<ORDER1>(P, ctx, s);
+    };
+    auto model_finish = [&]() {
+        af_row_store_updated(m_R, m_ia, m_ib, lds, m_rowbase, m_totaddr);
+        d_nx = (m_s == 15) ? T_nx : m_draw;
+        x_nx = af_recip((double)T_nx);
+    };
+    // arithmetic stage: shrink_range (:58-78) and the renormalisation loops (:126-150) of one symbol
+    auto code = [&](u32 cc, u32 dd, u32 TT, double xx) {
+        af_shrink(low, hm, cc, dd, TT, xx);
+        u32 k, m;
+        const bool edge = af_renorm_counts(low, hm, k, m);
+        if (__builtin_expect(edge || (k + pending > 32), 0)) {
+            u64 lo = low, hi = (u64)hm + 1;
+            while (hi < AF_HALF || lo > AF_HALF) {
+                if (hi < AF_HALF) {
+                    wr.put(0, 1);
+                    wr.put_run(1, pending);
+                    lo <<= 1;
+                    hi <<= 1;
+                } else {
+                    wr.put(1, 1);
+                    wr.put_run(0, pending);
+                    lo = (lo - AF_HALF) << 1;
+                    hi = (hi - AF_HALF) << 1;
+                }
+                pending = 0;
             }
-            if ((p & 3) == 0) {
-                word = cur.x;
-                cur.x = cur.y;
-                cur.y = cur.z;
-                cur.z = cur.w;
+            while (lo > AF_QTR && hi < 3ull * AF_QTR) {
+                pending += 1;
+                lo = (lo - AF_QTR) << 1;
+                hi = (hi - AF_QTR) << 1;
             }
+            low = (u32)lo;
+            hm = (u32)(hi - 1);
+        } else {
+            if (k > 0) {
+                // b0, then `pending` copies of !b0, then the other k-1 common bits
+                const u32 top = low >> (32 - k);
+                const u32 b0 = top >> (k - 1);
+                const u32 rest = top & ((1u << (k - 1)) - 1u);
+                const u32 pat = (1u << pending) - (b0 ^ 1u);  // pending <= 31 here
+                wr.put((pat << (k - 1)) | rest, k + pending);
+                pending = 0;
+            }
+            pending += m;
+            const u32 kt = k + m;  // <= 31
+            low = (low << kt) & 0x7FFFFFFFu;
+            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+        }
+    };
+
+    // Before the first symbol (c, d, T, 1/T) = (0, 1, 1, 1.0) makes the arithmetic stage a no-op (d == T keeps
+    // high, low += 0, nothing to renormalise), so every symbol runs the same body and one more `code` drains it.
+    const u32 n_words = (n + 3) >> 2;
+    if (n > 0) nextw = src[0];
+    for (u32 w = 0; w < n_words; ++w) {
+        // four symbols per 32-bit load, one word ahead.  The load is unconditional with its index clamped into
+        // the chunk and sits where nothing has to be merged with it: a load under a lane-dependent or periodic
+        // condition is copied into the loop-carried register at once, i.e. waited for at once (~1 us each).
+        u32 word = nextw;
+        nextw = src[min(w + 1, last_word)];
+        const u32 cnt = min(4u, n - 4 * w);
+#pragma unroll 1
+        for (u32 j = 0; j < cnt; ++j) {
             u32 s = word & 0xFFu;
             word >>= 8;
             if (s >= P.K) {
                 st |= SCL_ST_SYMBOL;
                 s = 0;
             }
-            const u32 rowbase = ctx * AF_CTX_BYTES + tid * 16;
-            const u32 sm1 = (s == 0) ? 0 : s - 1;
-            const u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + af_elem_addr(rowbase, sm1));
-            d_nx = *reinterpret_cast<const u16_lds *>(lds + af_elem_addr(rowbase, s));
-            c_nx = (s == 0) ? 0 : c_raw;
-            AfRow R;
-            R.a = *reinterpret_cast<const uint4_lds *>(lds + rowbase);
-            R.b = *reinterpret_cast<const uint4_lds *>(lds + rowbase + AF_HALF_BYTES);
-            T_nx = R.b.w >> 16;
-            const AfRow R2 = af_row_plus_mask(R, lds, s);  // update_model, :118 (after this symbol's lookup)
-            *reinterpret_cast<uint4_lds *>(lds + rowbase) = R2.a;
-            *reinterpret_cast<uint4_lds *>(lds + rowbase + AF_HALF_BYTES) = R2.b;
-            ctx = af_next_ctx(P, ctx, s);
-        }
-        if (p > 0) {
-            // ---- arithmetic of symbol p-1 ----
-            af_shrink(low, hm, cc, dd, TT);
-            u32 k, m;
-            const bool edge = af_renorm_counts(low, hm, k, m);
-            if (__builtin_expect(edge || (k + pending > 32), 0)) {
-                // literal loops of the reference, :126-150
-                u64 lo = low, hi = (u64)hm + 1;
-                while (hi < AF_HALF || lo > AF_HALF) {
-                    if (hi < AF_HALF) {
-                        wr.put(0, 1);
-                        wr.put_run(1, pending);
-                        lo <<= 1;
-                        hi <<= 1;
-                    } else {
-                        wr.put(1, 1);
-                        wr.put_run(0, pending);
-                        lo = (lo - AF_HALF) << 1;
-                        hi = (hi - AF_HALF) << 1;
-                    }
-                    pending = 0;
-                }
-                while (lo > AF_QTR && hi < 3ull * AF_QTR) {
-                    pending += 1;
-                    lo = (lo - AF_QTR) << 1;
-                    hi = (hi - AF_QTR) << 1;
-                }
-                low = (u32)lo;
-                hm = (u32)(hi - 1);
-            } else {
-                if (k > 0) {
-                    // b0, then `pending` copies of !b0, then the other k-1 common bits
-                    const u32 top = low >> (32 - k);
-                    const u32 b0 = top >> (k - 1);
-                    const u32 rest = top & ((1u << (k - 1)) - 1u);
-                    const u32 pn = (u32)pending;  // <= 31 here
-                    const u32 pat = (1u << pn) - (b0 ^ 1u);
-                    wr.put((pat << (k - 1)) | rest, k + pn);
-                    pending = 0;
-                }
-                pending += m;
-                const u32 kt = k + m;  // <= 31
-                low = (low << kt) & 0x7FFFFFFFu;
-                hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
-            }
+            const u32 cc = c_nx, dd = d_nx, TT = T_nx;
+            const double xx = x_nx;
+            model_issue(s);        // this symbol: LDS reads in flight ...
+            code(cc, dd, TT, xx);  // ... while the previous symbol is coded
+            model_finish();
         }
     }
+    code(c_nx, d_nx, T_nx, x_nx);
     pending += 1;  // termination, :153-159
     if (low <= AF_QTR) {
         wr.put(0, 1);
@@ -304,48 +333,31 @@ __global__ void __launch_bounds__(AF_THREADS)
     if (status) status[chunk] = st;
 }
 
-// ---- forward bit reader: 16-byte loads one block ahead, bits past the end of the stream read as 0 -------------
+// ---- forward bit reader: 4-byte loads, one word ahead; bits past the end of the stream read as 0 ---------------
 struct AfReader {
-    const uint4 *base;
-    u64 nblk;      // readable 16-byte blocks
-    u64 blk;       // next block to prefetch
-    uint4 cur, pf;
-    u32 wleft;     // words left in cur
-    u64 win;       // bit window, left-aligned
-    u32 nwin;      // valid bits in win (>= 32 between calls)
-    i64 rem;       // stream bits not yet moved into the window (may go negative)
+    const u32 *base;
+    u64 nwords;  // readable 32-bit words
+    u64 wi;      // index of the word held in `ahead`
+    u32 ahead;   // raw (memory-order) word wi
+    u64 win;     // bit window, left-aligned
+    u32 nwin;    // valid bits in win (>= 32 between calls)
+    i64 rem;     // stream bits not yet moved into the window (may go negative)
 
-    __device__ __forceinline__ uint4 load(u64 j) const { return (j < nblk) ? base[j] : make_uint4(0, 0, 0, 0); }
+    // index clamped instead of a conditional load (which would have to be waited for at once); words past the
+    // end of the stream are zeroed by `rem` below whatever was loaded
+    __device__ __forceinline__ u32 load(u64 j) const { return base[min(j, nwords - 1)]; }
     __device__ __forceinline__ u32 next_word() {
-        if (wleft == 0) {
-            cur = pf;
-            pf = load(blk++);
-            wleft = 4;
-        }
-        u32 v = __builtin_bswap32(cur.x);
-        cur.x = cur.y;
-        cur.y = cur.z;
-        cur.z = cur.w;
-        --wleft;
+        u32 v = __builtin_bswap32(ahead);
+        ahead = load(++wi);
         if (rem < 32) v = (rem <= 0) ? 0u : (v & ~(0xFFFFFFFFu >> rem));
         rem -= 32;
         return v;
     }
     __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 nbits) {
-        base = reinterpret_cast<const uint4 *>(in);
-        nblk = in_size_bytes >> 4;
-        const u64 b0 = bit_off >> 7;
-        cur = load(b0);
-        pf = load(b0 + 1);
-        blk = b0 + 2;
-        const u32 skipw = (u32)(bit_off >> 5) & 3u;
-        wleft = 4;
-        for (u32 i = 0; i < skipw; ++i) {
-            cur.x = cur.y;
-            cur.y = cur.z;
-            cur.z = cur.w;
-            --wleft;
-        }
+        base = reinterpret_cast<const u32 *>(in);
+        nwords = in_size_bytes >> 2;
+        wi = bit_off >> 5;
+        ahead = load(wi);
         const u32 skipb = (u32)bit_off & 31u;
         rem = (i64)nbits + skipb;
         const u64 hiw = next_word();
@@ -370,6 +382,7 @@ struct AfReader {
     }
 };
 
+template <bool ORDER1>
 __global__ void __launch_bounds__(AF_THREADS)
     aec_fast_decode_kernel(AecFastDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                            const u64 *__restrict__ bit_off, const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -399,68 +412,53 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (status) status[chunk] = st;
         return;
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(out_sym + chunk * out_stride);
+    u32 *dst = reinterpret_cast<u32 *>(out_sym + chunk * out_stride);
     u64 used = 32;
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
-    AfRow R;
-    R.a = *reinterpret_cast<const uint4_lds *>(lds + tid * 16);
-    R.b = *reinterpret_cast<const uint4_lds *>(lds + AF_HALF_BYTES + tid * 16);
-    uint4 ob = make_uint4(0, 0, 0, 0);
+    AfRow R = af_row_load(lds, tid * 32);
+    u32 T = P.total0;
     u32 oword = 0;
     for (u32 i = 0;; ++i) {
         // ---- decode_step_core, :177-201 ----
-        const u32 T = R.b.w >> 16;
-        const double rdd = (double)(hm - low) + 1.0;
-        const double xr = af_recip(rdd);
-        const double Td = (double)T;
+        const double xT = af_recip((double)T);  // independent of the search below
+        const double xr = af_recip((double)(hm - low) + 1.0);
         // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip), clamped for corrupt streams
-        const double num = __builtin_fma((double)(state - low) + 1.0, Td, -0.5);
+        const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
         u32 tgt = (u32)(num * xr);
         tgt = min(tgt, T - 1);
         const u32 tp = tgt | (tgt << 16);
-        u32 acc = 0;
-        acc = af_pk_count_gt(acc, tp, R.a.x);
-        acc = af_pk_count_gt(acc, tp, R.a.y);
-        acc = af_pk_count_gt(acc, tp, R.a.z);
-        acc = af_pk_count_gt(acc, tp, R.a.w);
-        acc = af_pk_count_gt(acc, tp, R.b.x);
-        acc = af_pk_count_gt(acc, tp, R.b.y);
-        acc = af_pk_count_gt(acc, tp, R.b.z);
-        acc = af_pk_count_gt(acc, tp, R.b.w);
-        // s = #{j : E[j] <= target} = 16 - #{E[j] > target}
-        u32 s = 16u + (u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16);
+        u32 acc0 = 0, acc1 = 0;
+        acc0 = af_pk_count_gt(acc0, tp, R.a.x);
+        acc1 = af_pk_count_gt(acc1, tp, R.a.y);
+        acc0 = af_pk_count_gt(acc0, tp, R.a.z);
+        acc1 = af_pk_count_gt(acc1, tp, R.a.w);
+        acc0 = af_pk_count_gt(acc0, tp, R.b.x);
+        acc1 = af_pk_count_gt(acc1, tp, R.b.y);
+        acc0 = af_pk_count_gt(acc0, tp, R.b.z);
+        acc1 = af_pk_count_gt(acc1, tp, R.b.w);
+        const u32 acc = af_pk_add(acc0, acc1);
+        // s = #{j >= 1 : X[j] <= target} = 15 - #{X[j] > target}   (X[0] = 0 always counts)
+        u32 s = 15u + (u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16);
         s = min(s, P.K - 1);
-        const u32 rowbase = ctx * AF_CTX_BYTES + tid * 16;
-        const u32 sm1 = (s == 0) ? 0 : s - 1;
-        const u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + af_elem_addr(rowbase, sm1));
-        const u32 d = *reinterpret_cast<const u16_lds *>(lds + af_elem_addr(rowbase, s));
-        const u32 c = (s == 0) ? 0 : c_raw;
-        const u32 nctx = af_next_ctx(P, ctx, s);
-        const u32 nbase = nctx * AF_CTX_BYTES + tid * 16;
-        AfRow Rn;  // issued before this row's write-back; patched below when it is the same row
-        Rn.a = *reinterpret_cast<const uint4_lds *>(lds + nbase);
-        Rn.b = *reinterpret_cast<const uint4_lds *>(lds + nbase + AF_HALF_BYTES);
-        const AfRow R2 = af_row_plus_mask(R, lds, s);  // update_model
-        *reinterpret_cast<uint4_lds *>(lds + rowbase) = R2.a;
-        *reinterpret_cast<uint4_lds *>(lds + rowbase + AF_HALF_BYTES) = R2.b;
-        const bool same = (nctx == ctx);
-        R.a = same ? R2.a : Rn.a;
-        R.b = same ? R2.b : Rn.b;
-        ctx = nctx;
-        af_shrink(low, hm, c, d, T);
+        const u32 rowbase = ctx * AF_CTX_BYTES + tid * 32;
+        const u32 totaddr = AF_TOT_BASE + ctx * (AF_THREADS * 4) + tid * 4;
+        const u32 ea = rowbase + 2 * s;
+        const u32 c = *reinterpret_cast<const u16_lds *>(lds + ea);
+        const u32 d_raw = *reinterpret_cast<const u16_lds *>(lds + ea + 2);
+        af_row_update(R, lds, rowbase, totaddr, s);  // update_model
+        ctx = af_next_ctx<ORDER1>(P, ctx, s);
+        const u32 Tcur = T;
+        // next symbol's row and total: issued now, needed only after the arithmetic below
+        R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
+        T = *reinterpret_cast<const u32_lds *>(lds + AF_TOT_BASE + ctx * (AF_THREADS * 4) + tid * 4);
+        const u32 d = (s == 15) ? Tcur : d_raw;
+        af_shrink(low, hm, c, d, Tcur, xT);
         // ---- symbol out ----
         oword |= s << (8 * (i & 3));
         if ((i & 3) == 3) {
-            const u32 q = (i >> 2) & 3;
-            if (q == 0) ob.x = oword;
-            if (q == 1) ob.y = oword;
-            if (q == 2) ob.z = oword;
-            if (q == 3) {
-                ob.w = oword;
-                dst[i >> 4] = ob;
-            }
+            dst[i >> 2] = oword;
             oword = 0;
         }
         if (i + 1 == n) break;  // before the renormalisation, :242-243
@@ -502,20 +500,7 @@ __global__ void __launch_bounds__(AF_THREADS)
             used += kt;
         }
     }
-    // tail of the last (partial) 16-symbol group
-    if ((n & 15) != 0) {
-        const u32 q = ((n - 1) >> 2) & 3;
-        if ((n & 3) != 0) {
-            if (q == 0) ob.x = oword;
-            if (q == 1) ob.y = oword;
-            if (q == 2) ob.z = oword;
-            if (q == 3) ob.w = oword;
-        }
-        if (q < 3) ob.w = 0;
-        if (q < 2) ob.z = 0;
-        if (q < 1) ob.y = 0;
-        dst[(n - 1) >> 4] = ob;
-    }
+    if ((n & 3) != 0) dst[(n - 1) >> 2] = oword;  // last, partial word (zero-padded inside the row)
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;
     u32 e = 0;
@@ -543,12 +528,13 @@ static AecFastDev aec_fast_dev(const scl_aec_model *m) {
     f.K = m->dev.K;
     f.nctx = (u32)m->dev.ctx_mod;
     f.ctx_magic = (65536u + f.nctx - 1) / f.nctx;
-    u32 E[16], acc = 0;
+    u32 X[16], acc = 0;
     for (u32 j = 0; j < 16; ++j) {
+        X[j] = acc;  // exclusive; entries past the alphabet hold the total
         if (j < f.K) acc += m->h_freq[j];
-        E[j] = acc;
     }
-    for (u32 r = 0; r < 8; ++r) f.initE[r] = E[2 * r] | (E[2 * r + 1] << 16);
+    f.total0 = acc;
+    for (u32 r = 0; r < 8; ++r) f.initX[r] = X[2 * r] | (X[2 * r + 1] << 16);
     return f;
 }
 
@@ -556,16 +542,26 @@ void aec_fast_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_str
                             u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
                             u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + AF_THREADS - 1) / AF_THREADS);
-    hipLaunchKernelGGL(aec_fast_encode_kernel, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m), d_sym,
-                       sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
-                       d_status);
+    if (m->dev.k == 1)
+        hipLaunchKernelGGL(aec_fast_encode_kernel<true>, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m),
+                           d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                           d_out_nbits, d_status);
+    else
+        hipLaunchKernelGGL(aec_fast_encode_kernel<false>, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m),
+                           d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                           d_out_nbits, d_status);
 }
 
 void aec_fast_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
                             const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + AF_THREADS - 1) / AF_THREADS);
-    hipLaunchKernelGGL(aec_fast_decode_kernel, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m), d_in,
-                       in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                       d_consumed, d_status);
+    if (m->dev.k == 1)
+        hipLaunchKernelGGL(aec_fast_decode_kernel<true>, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m), d_in,
+                           in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                           d_out_lens, d_consumed, d_status);
+    else
+        hipLaunchKernelGGL(aec_fast_decode_kernel<false>, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m),
+                           d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                           d_out_lens, d_consumed, d_status);
 }
