@@ -20,6 +20,11 @@
 // compares, carries, left shifts, SDWA, every VOP3 form, the multiplies and any SGPR operand cost twice that.
 // Hence: sign-bit arithmetic instead of compare+carry, model constants as template literals, fields laid out
 // so they need no extraction (k1 rides in the byte v_mad_u32_u24 ignores).
+// Measured on the 1 GiB batch: the branch-free form of put() below is slower at 4 waves per SIMD (encode 0.706 vs
+// 0.675 ms) and only wins when a lone wave per SIMD is latency bound (65 536 chunks: 0.240 vs 0.257 ms): off.
+#ifndef SCL_BRANCHFREE_PUT
+#define SCL_BRANCHFREE_PUT 0
+#endif
 template <int THREADS, bool HOLD_HALF_LINE = true>
 struct AnsBackWriter {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup

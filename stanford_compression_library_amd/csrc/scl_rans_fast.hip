@@ -142,16 +142,31 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     if (n_lines) cur.load(src16);
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
-        if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));  // prefetch the next line while this one is encoded
-#pragma nounroll
-        for (int half = 0; half < 2; ++half) {
+        // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
+        // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
+        if (!CHECK_SYM)
+            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+        else if (t + 1 < n_lines)  // (register budget of the checking variant)
+            nxt.load(src16 + 8 * (t + 1));
+        // straight-line code for the whole line: an inner loop holding only stores would make the compiler drain
+        // vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
+        if (!CHECK_SYM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, lds, tab, msh_rt);
                 if (i & 1) o.maybe_flush(lds);  // every 32 symbols: <= 12 new words on top of <= 15 pending
             }
+        } else {  // the symbol check needs the registers the unrolled form would spill: two half-line passes
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
+                for (int i = 0; i < 4; ++i) {
+                    rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, lds, tab, msh_rt);
+                    if (i & 1) o.maybe_flush(lds);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
+            }
         }
         cur = nxt;
     }
