@@ -309,3 +309,50 @@ def test_config2_roundtrip_properties(table, dev):
     h = float(-(p * np.log2(p)).sum())
     got = float(enc.nbits.double().mean().item() - 61) / chunk_len
     assert abs(got - h) < 0.05, (got, h)
+
+
+def _random_pow2_table(rng, K, m_log2):
+    """K frequencies >= 1 summing to 2^m_log2, from flat to extremely skewed"""
+    M = 1 << m_log2
+    alpha = float(rng.choice([0.05, 0.3, 1.0, 20.0]))
+    w = rng.dirichlet(np.full(K, alpha))
+    f = np.maximum(1, np.floor(w * (M - K)).astype(np.int64) + 1)
+    while f.sum() > M:
+        f[np.argmax(f)] -= 1
+    f[np.argmax(f)] += M - f.sum()
+    assert f.sum() == M and f.min() >= 1
+    return f.astype(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_fast_paths_vs_oracle(seed, dev):
+    """Differential test of the tuned kernels (rANS / tANS / range fast paths) on random power-of-two tables:
+    alphabets 2..256, totals 2^1..2^12, flat to extremely skewed, symbols drawn from the table and -- to hit the
+    longest fields -- from a uniform distribution; 40 ragged chunks per model, every stream equal to the oracle's,
+    every decode equal to the input with the exact bit count."""
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.choice([2, 3, 5, 16, 17, 100, 255, 256]))
+    m_log2 = int(rng.integers(max(1, int(np.ceil(np.log2(K)))), 13))
+    f = _random_pow2_table(rng, K, m_log2)
+    cap = 640
+    lens = np.concatenate([[0, 1, 127, 128, 129, 255, 256, 257, 640], rng.integers(0, cap + 1, 31)]).astype(np.int32)
+    p = f / f.sum()
+    sym = np.stack([rng.choice(K, cap, p=p) if c % 3 else rng.integers(0, K, cap) for c in range(lens.size)]).astype(np.uint8)
+    d_sym, d_lens = torch.from_numpy(sym).to(dev), torch.from_numpy(lens).to(dev)
+    cases = [("rans", models.RansModel(f.tolist(), 1 << 16, 1, 32), lambda s: orc.rans_encode(s, f)),
+             ("range", models.RangeModel(f.tolist(), 32, 32), lambda s: orc.range_encode(s, f))]
+    if m_log2 <= 12:
+        cases.append(("tans", models.TansModel(f.tolist(), 1, 32), lambda s: orc.tans_encode(s, f, RF=1)))
+    for name, model, o_enc in cases:
+        enc = model.encode_batch(d_sym, lens=d_lens)
+        dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+        torch.cuda.synchronize()
+        assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0, name
+        data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+        dec = dec.cpu().numpy()
+        assert np.array_equal(dlens.cpu().numpy(), lens) and np.array_equal(used.cpu().numpy(), nbits), name
+        for c in range(lens.size):
+            rb, rn = o_enc(sym[c, :lens[c]])
+            assert int(nbits[c]) == rn, f"{name} K={K} M=2^{m_log2} chunk {c}"
+            assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} chunk {c}"
+            assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} chunk {c}"
