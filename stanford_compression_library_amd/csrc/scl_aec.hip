@@ -23,7 +23,11 @@
 // Model state lives in caller-provided device scratch, one private region per chunk:
 //   IID    : K   u32 counts, initialised by the lane from the initial frequencies
 //   ORDERK : K^(k+1) u32 cells holding (count - 1); the host zero-fills the scratch (= all-ones counts,
-//            probability_models.py:110) with one hipMemsetAsync before the launch.
+//            probability_models.py:110) with one hipMemsetAsync before the launch.  Alphabets of 32 symbols and
+//            more store every row in two levels -- 16 block totals, then the counts in blocks of 16, all as
+//            (count - 1) -- so that a lookup is two 64-byte reads issued together (ONE memory round trip; these
+//            tables live in HBM/L2 and the kernel is bound by that latency), an update two stores, and the
+//            decoder's search two dependent 64-byte reads, instead of a scan of the whole row.
 #include <string.h>
 
 #include "scl_aec_internal.h"
@@ -64,7 +68,9 @@ struct LaneModel {
             for (u32 j = 0; j < P->K; ++j) cnt[j] = P->d_freq[j];
         }
     }
-    __device__ __forceinline__ u64 row_base() const { return (P->kind == SCL_MODEL_ORDERK) ? ctx * P->K : 0; }
+    __device__ __forceinline__ u64 row_base() const {
+        return (P->kind == SCL_MODEL_ORDERK) ? ctx * ((!LDS16 && P->fenwick) ? P->row_cells : P->K) : 0;
+    }
     // cumulative count below s, frequency of s and total of the current distribution (freqs_current)
     __device__ __forceinline__ void lookup(u32 s, const u32 *s_f, const u32 *s_c, u64 &c, u64 &f, u64 &T) const {
         if (P->kind == SCL_MODEL_FIXED) {
@@ -74,6 +80,24 @@ struct LaneModel {
             return;
         }
         const u64 rb = row_base();
+        if (!LDS16 && P->fenwick) {  // count[j] = 1 + extra[j]
+            u32 bt[16], cb[16];
+            load16(bt, rb);
+            load16(cb, rb + 16 + (s & ~15u));
+            const u32 b = s >> 4, w = s & 15u;
+            u64 below = 0, tot = 0, fs = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                tot += bt[j];
+                below += (j < b) ? bt[j] : 0u;
+                below += (j < w) ? cb[j] : 0u;
+                fs = (j == w) ? cb[j] : fs;
+            }
+            c = s + below;
+            f = 1 + fs;
+            T = P->K + tot;
+            return;
+        }
         u64 acc = 0, cs = 0, fs = 0;
         for (u32 j = 0; j < P->K; ++j) {
             const u64 v = rd(rb + j);
@@ -87,8 +111,23 @@ struct LaneModel {
         f = fs;
         T = acc;
     }
+    // 16 consecutive cells (64 bytes, 64-byte aligned) as four 16-byte loads issued back to back
+    __device__ __forceinline__ void load16(u32 (&v)[16], u64 cell) const {
+        const uint4 *p = reinterpret_cast<const uint4 *>(cnt + cell);
+        const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        v[0] = q0.x, v[1] = q0.y, v[2] = q0.z, v[3] = q0.w, v[4] = q1.x, v[5] = q1.y, v[6] = q1.z, v[7] = q1.w;
+        v[8] = q2.x, v[9] = q2.y, v[10] = q2.z, v[11] = q2.w, v[12] = q3.x, v[13] = q3.y, v[14] = q3.z, v[15] = q3.w;
+    }
     __device__ __forceinline__ u64 total(const u32 *) const {
         if (P->kind == SCL_MODEL_FIXED) return P->total0;
+        if (!LDS16 && P->fenwick) {
+            u32 bt[16];
+            load16(bt, row_base());
+            u64 tot = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) tot += bt[j];
+            return P->K + tot;
+        }
         const u64 rb = row_base();
         u64 acc = 0;
         for (u32 j = 0; j < P->K; ++j) acc += rd(rb + j);
@@ -110,6 +149,38 @@ struct LaneModel {
             return lo;
         }
         const u64 rb = row_base();
+        if (!LDS16 && P->fenwick) {  // largest s <= K-1 with c[s] = s + extras below s <= cmax: block, then symbol
+            u32 bt[16], cb[16];
+            load16(bt, rb);
+            const u32 nblk = (P->K + 15) >> 4;
+            u32 b = 0;
+            u64 g = 0, run = 0;  // run = c[16 * j] while scanning
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                if (j < nblk && run <= cmax) {
+                    b = j;
+                    g = run;
+                }
+                run += 16 + bt[j];
+            }
+            load16(cb, rb + 16 + 16 * b);
+            const u32 wmax = min(15u, P->K - 1 - 16 * b);
+            u32 w = 0;
+            u64 gw = g, fw = cb[0];
+            run = g;
+#pragma unroll
+            for (u32 j = 0; j < 16; ++j) {
+                if (j <= wmax && run <= cmax) {
+                    w = j;
+                    gw = run;
+                    fw = cb[j];
+                }
+                run += 1 + cb[j];
+            }
+            c = gw;
+            f = 1 + fw;
+            return 16 * b + w;
+        }
         u64 acc = 0;
         u32 j = 0;
         for (; j + 1 < P->K; ++j) {
@@ -121,8 +192,16 @@ struct LaneModel {
         f = rd(rb + j);
         return j;
     }
-    __device__ __forceinline__ void update(u32 s) {
+    __device__ __forceinline__ void update(u32 s, u64 f_before) {
         if (P->kind == SCL_MODEL_FIXED) return;
+        if (!LDS16 && P->fenwick) {  // order-k, probability_models.py:143-160
+            const u64 rb = row_base();
+            cnt[rb + 16 + s] = (u32)f_before;        // extra[s] = count - 1 = f_before after the increment
+            atomicAdd(&cnt[rb + (s >> 4)], 1u);        // block total (no return value: fire and forget)
+            if (P->k > 0) ctx = (ctx * P->K + s) % P->ctx_mod;
+            if (f_before + 1 >= P->max_total) bad = 1;
+            return;
+        }
         if (P->kind == SCL_MODEL_IID) {  // probability_models.py:83-92
             wr(s, rd(s) + 1);
             u64 tot = 0;
@@ -185,7 +264,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
         const u64 rng = high - low;  // shrink_range :70-77
         high = low + (rng * (cs + fs)) / T;
         low = low + (rng * cs) / T;
-        mdl.update(s);  // :118
+        mdl.update(s, fs);  // :118
         while (high < HALF || low > HALF) {  // E1 / E2, :126-143
             if (high < HALF) {
                 w.put(0, 1);
@@ -280,7 +359,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
         high = low + (rng * (cs + fs)) / T;
         low = low + (rng * cs) / T;
         dst[ndec++] = (u8)s;
-        mdl.update(s);
+        mdl.update(s, fs);
         if (ndec == n) break;  // before the renormalisation, :242-243
         while (high < HALF || low > HALF) {
             if (high < HALF) {
@@ -335,6 +414,8 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     m->dev.max_total = max_total;
     m->dev.ctx_mod = 1;
     m->dev.cells = 0;
+    m->dev.fenwick = 0;
+    m->dev.row_cells = 0;
     u32 freq[256], cum[256];
     u64 tot = 0;
     if (model_kind == SCL_MODEL_ORDERK) {
@@ -355,6 +436,11 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
             return SCL_E_PARAM;
         }
         m->dev.cells = cells;
+        if (K >= 32 && cells > AEC_LDS_CELLS) {  // two-level rows: 16 block totals + counts in blocks of 16
+            m->dev.fenwick = 1;
+            m->dev.row_cells = 16 + 16 * ((K + 15) / 16);
+            m->dev.cells = m->dev.ctx_mod * m->dev.row_cells;
+        }
         for (u32 i = 0; i < K; ++i) {
             freq[i] = 1;
             cum[i] = i;

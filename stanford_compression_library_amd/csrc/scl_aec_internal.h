@@ -13,6 +13,8 @@ struct AecDev {
     const u32 *d_freq;  // [K] initial frequencies (FIXED / IID)
     const u32 *d_cum;   // [K] exclusive cumulative of d_freq (FIXED)
     u32 total0;         // sum of initial frequencies
+    u32 fenwick;        // ORDERK with a large alphabet: two-level rows of (count - 1), see scl_aec.hip
+    u32 row_cells;      // two-level rows: 16 block totals + 16 * ceil(K / 16) counts
 };
 
 struct scl_aec_model {

@@ -109,7 +109,7 @@ def test_batch_ragged_vs_oracle(name, dev):
         assert np.array_equal(dec2[c, :lens[c]].cpu().numpy(), sym[c, :lens[c]])
 
 
-@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0)])
+@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0)])
 def test_batch_aec_orderk_vs_oracle(K, k, dev):
     """order-k adaptive arithmetic coding, private model per lane (BASELINE.json configs[3] shape)"""
     n_chunks, n = 12, 700
