@@ -311,6 +311,66 @@ def test_config2_roundtrip_properties(table, dev):
     assert abs(got - h) < 0.05, (got, h)
 
 
+def _check_sample_against_oracle(enc, sample, o_enc, sym_rows):
+    offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c, row in zip(sample, sym_rows):
+        rb, rn = o_enc(row)
+        assert int(nbits[c]) == rn, f"chunk {c}"
+        lo = int(offs[c]) // 8
+        window = enc.data[lo:lo + (rn + 7) // 8 + 2].cpu().numpy()
+        bits = np.unpackbits(window)[int(offs[c]) % 8:][:rn]
+        assert np.array_equal(bits, np.unpackbits(rb)[:rn]), f"chunk {c}"
+
+
+def test_config3_range_coder_full_size_properties(dev):
+    """BASELINE.json configs[2]: 32-bit range coder on 1 GiB of uniform bytes (f = 1, M = 256), 262 144 chunks of
+    4 KiB.  decode(encode(x)) == x for every chunk, consumed == produced, every stream is the 32-bit header plus
+    4096 + 3 bytes, a few more after a carry-less range reset (SURVEY 8a/a10 measured 32 824 bits), and a fixed sample equals the oracle bit for bit."""
+    freq = np.ones(256, dtype=np.int64)
+    n_chunks, chunk_len = 262144, 4096
+    model = models.RangeModel(freq.tolist(), 32, 32)
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=3, device=dev)
+    enc = model.encode_batch(sym)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    assert torch.equal(dec[:, :chunk_len], sym) and torch.equal(used, enc.nbits)
+    assert int(dlens.min()) == chunk_len == int(dlens.max())
+    nb = enc.nbits.cpu().numpy()
+    assert np.all((nb - 32) % 8 == 0) and 4099 <= (nb.min() - 32) // 8 and (nb.max() - 32) // 8 <= 4104, np.unique(nb)
+    assert np.mean(nb <= 32832) > 0.9  # 4099 or 4100 bytes almost always
+    sample = [0, 1, 4095, 131072, n_chunks - 1]
+    _check_sample_against_oracle(enc, sample, lambda s: orc.range_encode(s, freq), [sym[c].cpu().numpy() for c in sample])
+
+
+def test_config4_order1_arithmetic_full_size_properties(dev):
+    """BASELINE.json configs[3]: order-1 adaptive arithmetic coding of a Markov-1 source, K = 16, per-lane context
+    tables in LDS, 65 536 chunks of 4 KiB: round trip for every chunk, consumed == produced, oracle equality on a
+    sample, and the code length is within 3 % of the source's empirical conditional entropy + learning cost."""
+    K, n_chunks, chunk_len = 16, 65536, 4096
+    base = np.stack([bench_data.markov1_host(K, chunk_len, seed=400 + c) for c in range(128)])
+    sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 128, 1)
+    model = models.AecModel(2, None, K, 1, 1 << 30, 32, 32)
+    assert model.fast_path(chunk_len)
+    enc = model.encode_batch(sym)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    assert torch.equal(dec[:, :chunk_len], sym) and torch.equal(used, enc.nbits)
+    sample = [0, 1, 127, 128, 4095, n_chunks - 1]
+    _check_sample_against_oracle(enc, sample, lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=1),
+                                 [base[c % 128] for c in sample])
+    # identical inputs -> identical streams, whatever lane / workgroup coded them
+    nb = enc.nbits.view(n_chunks // 128, 128)
+    assert bool((nb == nb[0:1]).all())
+    # adaptive code length: sum over symbols of -log2((count + 1) / (total + K)) computed on the host for chunk 0
+    cnt = np.ones((K, K)); prev = 0; ideal = 0.0
+    for x in base[0]:
+        ideal -= np.log2(cnt[prev, x] / cnt[prev].sum()); cnt[prev, x] += 1; prev = int(x)
+    got = int(enc.nbits[0].item()) - 32
+    assert abs(got - ideal) < 0.002 * ideal + 8, (got, ideal)
+
+
 def _random_pow2_table(rng, K, m_log2):
     """K frequencies >= 1 summing to 2^m_log2, from flat to extremely skewed"""
     M = 1 << m_log2
