@@ -134,13 +134,15 @@ def main():
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)))
-        world = dist.get_world_size()
     lib.require_device()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
+                                device_id=dev)
+        world = dist.get_world_size()
 
     freq = {"t256": bench_data.t256_table, "uniform": bench_data.uniform256_table,
             "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
@@ -171,7 +173,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
         step()
