@@ -40,6 +40,8 @@ def parse_args():
                     help="t256: Dirichlet table M=4096; uniform: f=16, M=4096; uniform1: f=1, M=256 (configs[2])")
     ap.add_argument("--coder", choices=["rans", "tans", "range", "aec"], default="rans")
     ap.add_argument("--aec-K", type=int, default=16, help="alphabet of the order-1 adaptive arithmetic coder (configs[3])")
+    ap.add_argument("--aec-model", choices=["order1", "fixed"], default="order1",
+                    help="arithmetic coder: order-1 adaptive model on a Markov-1 source, or FixedFreqModel(--table) on i.i.d. symbols")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
     ap.add_argument("--sym-pad", type=int, default=0, help="experiment: extra bytes between input rows")
@@ -53,6 +55,9 @@ def make_model(args, freq):
         return models.RansModel(freq.tolist(), 1 << 16, 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1 << 16)
     if args.coder == "tans":
         return models.TansModel(freq.tolist(), 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1)
+    if args.coder == "aec" and args.aec_model == "fixed":
+        return (models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
+                dict(PRECISION=32, model=f"FixedFreqModel({args.table})"))
     if args.coder == "aec":
         K = args.aec_K
         return (models.AecModel(backend_lib_consts()["MODEL_ORDERK"], None, K, 1, 1 << 30, 32, 32),
@@ -148,7 +153,7 @@ def main():
             "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
     model, coder_params = make_model(args, freq)
     n_chunks, chunk_len = args.chunks, args.chunk_len
-    if args.coder == "aec":
+    if args.coder == "aec" and args.aec_model == "order1":
         # configs[3]: Markov-1 source (S4 of SURVEY 8d); 256 distinct chunks generated on the host, tiled to the batch
         base = np.stack([bench_data.markov1_host(args.aec_K, chunk_len, seed=4 + 1000 * rank + i) for i in range(256)])
         sym = torch.from_numpy(base).to(dev).repeat((n_chunks + 255) // 256, 1)[:n_chunks].contiguous()
@@ -253,7 +258,7 @@ def main():
             "config": {"workload": f"batched {args.coder}: {n_chunks} independent "
                                    f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
                                    + (f"256-symbol static table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M"
-                                      if args.coder != "aec"
+                                      if (args.coder != "aec" or args.aec_model == "fixed")
                                       else f"order-1 adaptive model, K={args.aec_K}, Markov-1 source"),
                        "coder": args.coder, **coder_params, "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
                        "bits_per_symbol_out": round(bits_per_symbol, 4), "sharding": f"{world} x independent shards"},

@@ -502,7 +502,7 @@ extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chu
 }
 
 extern "C" int scl_aec_fast_path(const scl_aec_model *m, uint64_t max_symbols) {
-    return (m && aec_fast_ok(m, max_symbols)) ? 1 : 0;
+    return (m && (aec_fast_ok(m, max_symbols) || aec_static_ok(m))) ? 1 : 0;
 }
 
 // per-lane context tables in LDS: at most 256 cells, counts (initial + one per symbol) must fit 16 bits
@@ -541,6 +541,14 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
+    // static model: shared table in LDS, line-granular I/O (scl_aec_static.hip)
+    if (aec_static_ok(m) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 && (out_stride & 15) == 0 &&
+        out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
+        aec_static_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                 d_out_bit_offset, d_out_nbits, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     if (!aec_use_lds(m, chunk_len)) {
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
         if (rc) return rc;
@@ -573,6 +581,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
         (out_stride & 15) == 0 && out_stride >= scl_round_up(out_cap, 16)) {
         aec_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                out_cap, d_out_lens, d_consumed, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
+    if (aec_static_ok(m) && ((uintptr_t)d_in & 15) == 0 && in_size_bytes < (1ull << 34) &&
+        ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0 && out_stride >= out_cap) {
+        aec_static_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                 out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }

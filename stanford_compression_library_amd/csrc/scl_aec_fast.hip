@@ -31,6 +31,7 @@
 //    straight to the slot (4-byte stores, L2 merges them); symbols arrive four per 32-bit load, one word ahead,
 //    the load unconditional so that it is not waited for at once.
 #include "scl_aec_internal.h"
+#include "scl_aec_math.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -51,8 +52,6 @@ typedef uint4 __attribute__((may_alias)) uint4_lds;
 #define AF_LUT_BASE (AF_TOT_BASE + AF_TOT_BYTES)
 #define AF_LUT_BYTES 512
 #define AF_LDS_BYTES (AF_LUT_BASE + AF_LUT_BYTES)
-#define AF_HALF 0x80000000u
-#define AF_QTR 0x40000000u
 
 struct AecFastDev {
     u32 K;          // alphabet size 2..16
@@ -70,16 +69,6 @@ __device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
     s16x2 d = __builtin_bit_cast(s16x2, t) - __builtin_bit_cast(s16x2, e);
     d = d >> (s16x2)(15);
     return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, acc) + d));
-}
-
-// 1 / v for an integer 1 <= v <= 2^32 held exactly in a double, relative error < 2^-50
-__device__ __forceinline__ double af_recip(double v) {
-    double x = (double)__builtin_amdgcn_rcpf((float)v);
-    double e = __builtin_fma(-v, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    e = __builtin_fma(-v, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    return x;
 }
 
 struct AfRow {
@@ -138,51 +127,36 @@ __device__ __forceinline__ AfRow af_row_update(const AfRow &R, char *lds, u32 ro
     return o;
 }
 
-// shrink_range (:58-78) on (low, hm = high - 1); c, d = c + f, T from the model, x = 1/T
-__device__ __forceinline__ void af_shrink(u32 &low, u32 &hm, u32 c, u32 d, u32 T, double x) {
-    const double rd = (double)(hm - low) + 1.0;
-    const u32 q1 = (u32)(__builtin_fma(rd, (double)c, 0.5) * x);
-    const u32 q2 = (u32)(__builtin_fma(rd, (double)d, 0.5) * x);
-    hm = (d == T) ? hm : low + q2 - 1;  // (rng*T)//T == rng: high is unchanged (and rng may be 2^32)
-    low = low + q1;
-}
-
-// closed-form renormalisation counts; returns true if the literal loops must be used for this symbol:
-// ctz(low) + k + m + 1 >= 32 for low != 0, likewise for high (v_ffbl of 0 is -1, which wraps to "no")
-__device__ __forceinline__ bool af_renorm_counts(u32 low, u32 hm, u32 &k, u32 &m) {
-    k = (u32)__builtin_clz(low ^ hm);  // low != hm: the interval holds more than one value
-    const u32 z = ((low & ~hm) << k) << 1;
-    m = (u32)__builtin_clz(~z);
-    const u32 sh = k + m + 1;  // <= 32
-    const u32 e_lo = (u32)(__builtin_ffs((int)low) - 1) + sh;
-    const u32 e_hi = (u32)(__builtin_ffs((int)(hm + 1)) - 1) + sh;
-    return max(e_lo, e_hi) >= 32;
-}
-
 // ---- forward bit writer: completed big-endian words go straight to the slot (4-byte stores; the stream is a
 // third of the input and L2 merges them -- a register FIFO costs ~50 phi copies per symbol, an LDS ring does not fit)
 struct AfWriter {
-    u64 acc;
-    u32 nacc;  // < 32 pending bits in acc
+    u32 hi;    // pending bits, right-aligned (the oldest is the most significant), < 32 of them
+    u32 nacc;  // number of pending bits
     u32 *dst;
     u32 nwords;
 
     __device__ __forceinline__ void init(u8 *slot) {
-        acc = 0;
+        hi = 0;
         nacc = 0;
         nwords = 0;
         dst = reinterpret_cast<u32 *>(slot);
     }
     __device__ __forceinline__ void put(u32 v, u32 nb) {  // v < 2^nb, nb <= 32
-        acc = (acc << nb) | v;
-        nacc += nb;
-        if (nacc >= 32) {
-            nacc -= 32;
+        // 32-bit arithmetic on purpose: see AnsFwdWriter::put (scl_ans_fast_io.h)
+        const u32 tot = nacc + nb;
+        if (tot >= 32) {
+            const u32 r = tot - 32;  // <= 31; nb - r = 32 - nacc
+            const u32 word = (r == 0) ? ((hi << (nb & 31)) | v) : ((hi << (nb - r)) | (v >> r));
 #if AF_ABLATE == 1
             nwords++;
 #else
-            dst[nwords++] = __builtin_bswap32((u32)(acc >> nacc));
+            dst[nwords++] = __builtin_bswap32(word);
 #endif
+            hi = v & ((1u << r) - 1u);
+            nacc = r;
+        } else {
+            hi = (hi << nb) | v;
+            nacc = tot;
         }
     }
     __device__ __forceinline__ void put_run(u32 bit, u32 count) {
@@ -194,7 +168,7 @@ struct AfWriter {
     }
     __device__ __forceinline__ u64 finish() {
         const u64 total = (u64)nwords * 32 + nacc;
-        if (nacc) dst[nwords] = __builtin_bswap32((u32)(acc << (32 - nacc)));
+        if (nacc) dst[nwords] = __builtin_bswap32(hi << (32 - nacc));
         return total;
     }
 };

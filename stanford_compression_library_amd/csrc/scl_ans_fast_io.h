@@ -159,9 +159,15 @@ struct Line128 {
     }
 };
 
-template <int THREADS>
+// ZERO_PAST_END: bits after the last bit of the stream read as 0 whatever the buffer holds there (the arithmetic
+// decoder's state register looks 32 bits ahead, arithmetic_coding.py:222-229, :258-261); the ANS decoders never
+// look at what they do not consume and leave it off.
+template <int THREADS, bool ZERO_PAST_END = false>
 struct AnsBitReader {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
+    u32 wabs;      // ZERO_PAST_END: index (from the buffer start) of the next word that enters the ring
+    u32 end_word;  //                index of the word holding the first bit after the stream
+    u32 end_mask;  //                bits of that word which still belong to the stream
     const uint4 *base;
     u64 n_blocks16;  // readable 16-byte blocks
     u64 next_line;   // index of the next 128-byte line to prefetch
@@ -185,13 +191,27 @@ struct AnsBitReader {
                                               const uint4 &q3) {
         char *r = lds + wa;
         const uint4 blk[4] = {q0, q1, q2, q3};
+        if (ZERO_PAST_END && wabs + 16 > end_word) {  // the half that holds the end of the stream, or lies past it
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32 *>(r + (4 * i + 0) * THREADS * 4) = __builtin_bswap32(blk[i].x);
-            *reinterpret_cast<u32 *>(r + (4 * i + 1) * THREADS * 4) = __builtin_bswap32(blk[i].y);
-            *reinterpret_cast<u32 *>(r + (4 * i + 2) * THREADS * 4) = __builtin_bswap32(blk[i].z);
-            *reinterpret_cast<u32 *>(r + (4 * i + 3) * THREADS * 4) = __builtin_bswap32(blk[i].w);
+            for (int i = 0; i < 4; ++i) {
+                const u32 w4[4] = {blk[i].x, blk[i].y, blk[i].z, blk[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 wi = wabs + 4 * i + j;
+                    const u32 keep = (wi < end_word) ? 0xFFFFFFFFu : (wi == end_word ? end_mask : 0u);
+                    *reinterpret_cast<u32 *>(r + (4 * i + j) * THREADS * 4) = __builtin_bswap32(w4[j]) & keep;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<u32 *>(r + (4 * i + 0) * THREADS * 4) = __builtin_bswap32(blk[i].x);
+                *reinterpret_cast<u32 *>(r + (4 * i + 1) * THREADS * 4) = __builtin_bswap32(blk[i].y);
+                *reinterpret_cast<u32 *>(r + (4 * i + 2) * THREADS * 4) = __builtin_bswap32(blk[i].z);
+                *reinterpret_cast<u32 *>(r + (4 * i + 3) * THREADS * 4) = __builtin_bswap32(blk[i].w);
+            }
         }
+        if (ZERO_PAST_END) wabs += 16;
         wa ^= 16 * THREADS * 4;
         nwr += 16;
     }
@@ -214,10 +234,17 @@ struct AnsBitReader {
             }
         }
     }
-    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid) {
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid,
+                                         u32 nbits = 0) {
         base = reinterpret_cast<const uint4 *>(in);
         n_blocks16 = in_size_bytes >> 4;
         const u64 j0 = bit_off >> 10;
+        if (ZERO_PAST_END) {  // (streams and buffers are below 2^37 bits: word indices fit 32 bits)
+            const u64 end = bit_off + nbits;
+            wabs = (u32)(j0 * 32);
+            end_word = (u32)(end >> 5);
+            end_mask = ~(0xFFFFFFFFu >> (end & 31u)) & (0u - (u32)((end & 31u) != 0));
+        }
         wa = tid * 4;
         nwr = 0;
         load_line(j0);
@@ -262,3 +289,109 @@ struct AnsBitReader {
     }
 };
 
+
+// Forward twin of AnsBackWriter for streams that grow front to back (arithmetic coder): completed big-endian
+// words go to the per-lane LDS ring ([word][thread], at LDS offset 0) and leave for memory as whole 128-byte lines
+// (the first 64-byte half waits in registers), so that a lane only ever stores whole, aligned lines.
+template <int THREADS>
+struct AnsFwdWriter {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
+    u32 hi;    // pending bits, right-aligned (the oldest is the most significant), < 32 of them
+    u32 nacc;  // number of pending bits
+    u32 ra;    // LDS byte address of the ring word that completes next
+    u32 fa;    // LDS byte address of the oldest unflushed word
+    u32 pend;  // completed words not yet stored to memory
+    u32 nfl;   // words already stored to memory (a held half line counts as stored)
+    u8 *slot;
+    uint4 held[4];
+    u32 have_held;
+
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_) {
+        hi = 0;
+        nacc = 0;
+        ra = tid * 4;
+        fa = tid * 4;
+        pend = 0;
+        nfl = 0;
+        slot = slot_;
+        have_held = 0;
+        held[0] = held[1] = held[2] = held[3] = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void put(char *lds, u32 v, u32 w) {  // v < 2^w, w <= 32
+        const u32 tot = nacc + w;
+        if (tot >= 32) {
+            const u32 r = tot - 32;  // <= 31
+            // 32-bit arithmetic on purpose.  The obvious (u32)(t >> r) on a 64-bit t compiled to v_lshrrev_b64 with
+            // a just-computed VGPR shift amount and, at full occupancy, stored a wrong word about once in 10^8
+            // (tools/stress_aec_static.py: ~3 words per 1 GiB encode held the bits accumulated BEFORE this call);
+            // this form has been stress-tested clean.  w - r = 32 - nacc is in [1, 32); r == 0 means w == 32 - nacc.
+            const u32 word = (r == 0) ? ((hi << (w & 31)) | v) : ((hi << (w - r)) | (v >> r));
+            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32(word);
+            ra = (ra + THREADS * 4) & (RING_BYTES - 1);
+            ++pend;
+            hi = v & ((1u << r) - 1u);
+            nacc = r;
+        } else {
+            hi = (hi << w) | v;  // tot < 32, so w < 32
+            nacc = tot;
+        }
+    }
+    // 16 pending words leave the ring at a time; call after at most 16 new words
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        if (pend >= 16) {
+            const char *r = lds + fa;
+            u32 w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * THREADS * 4);
+            const uint4 q0 = make_uint4(w[0], w[1], w[2], w[3]), q1 = make_uint4(w[4], w[5], w[6], w[7]);
+            const uint4 q2 = make_uint4(w[8], w[9], w[10], w[11]), q3 = make_uint4(w[12], w[13], w[14], w[15]);
+            if (have_held) {  // second half of the line whose first half is held
+                uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+                p[0] = held[0];
+                p[1] = held[1];
+                p[2] = held[2];
+                p[3] = held[3];
+                p[4] = q0;
+                p[5] = q1;
+                p[6] = q2;
+                p[7] = q3;
+                have_held = 0;
+            } else {
+                held[0] = q0;
+                held[1] = q1;
+                held[2] = q2;
+                held[3] = q3;
+                have_held = 1;
+            }
+            nfl += 16;
+            pend -= 16;
+            fa ^= 16 * THREADS * 4;
+        }
+    }
+    __device__ __forceinline__ void put_run(char *lds, u32 bit, u32 count) {  // `count` copies of `bit`
+        while (count >= 32) {
+            put(lds, bit ? 0xFFFFFFFFu : 0u, 32);
+            maybe_flush(lds);
+            count -= 32;
+        }
+        if (count) put(lds, bit ? ((1u << count) - 1u) : 0u, count);
+    }
+    __device__ __forceinline__ u64 finish(char *lds) {  // returns the stream length in bits
+        maybe_flush(lds);
+        if (have_held) {
+            uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+            p[0] = held[0];
+            p[1] = held[1];
+            p[2] = held[2];
+            p[3] = held[3];
+        }
+        u32 *dst = reinterpret_cast<u32 *>(slot) + nfl;
+        u32 a = fa;
+        for (u32 j = 0; j < pend; ++j) {
+            dst[j] = *reinterpret_cast<const u32 *>(lds + a);
+            a = (a + THREADS * 4) & (RING_BYTES - 1);
+        }
+        if (nacc) dst[pend] = __builtin_bswap32(hi << (32 - nacc));  // zero bits behind the stream
+        return (u64)(nfl + pend) * 32 + nacc;
+    }
+};

@@ -229,6 +229,70 @@ def test_batch_aec_lds_table_kernels_short_chunks(dev):
             assert np.array_equal(got, rb), f"K={K} chunk {c}"
 
 
+@pytest.mark.parametrize("K,T", [(2, 5), (17, 1000), (256, 4096), (100, 4097), (256, 65536), (3, 65536)])
+def test_batch_aec_static_model_kernels_vs_oracle(K, T, dev):
+    """scl_aec_static.hip (FixedFreqModel: shared table in LDS, line-granular I/O): 300 ragged chunks incl. whole
+    128-symbol lines and every tail length, streams equal to the oracle's, decode from the slots and from a
+    bit-adjacent buffer with garbage after every stream (exact consumed-bit counts).  Totals <= 4096 use the
+    slot -> symbol table, larger ones the binary search."""
+    rng = np.random.default_rng(77 * K + T)
+    f = np.maximum(1, np.floor(rng.dirichlet(np.full(K, 0.5)) * (T - K)).astype(np.int64) + 1)
+    f[np.argmax(f)] += T - f.sum()
+    assert f.sum() == T and f.min() >= 1
+    f = f.astype(np.uint32)
+    cap = 700
+    lens = np.concatenate([[0, 1, 2, 3, 4, 5, 127, 128, 129, 255, 256, 257, 383, 384, 640, 700],
+                           rng.integers(0, cap + 1, 284)]).astype(np.int32)
+    n_chunks = lens.size
+    model = models.AecModel(0, f.tolist(), K, 0, 1 << 30, 32, 32)
+    assert model.fast_path(cap)
+    o_enc = lambda s: orc.aec_encode(s, orc.MODEL_FIXED, K, f_init=f)
+    o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_FIXED, K, f_init=f)
+    sym = rng.choice(K, (n_chunks, 704), p=f / f.sum()).astype(np.uint8)
+    sym[5] = 0
+    sym[6] = K - 1
+    sym[7] = int(np.argmin(f))  # the rarest symbol over and over: longest renormalisations
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    ref = [o_enc(sym[c, :lens[c]]) for c in range(n_chunks)]
+    for c, (rb, rn) in enumerate(ref):
+        assert int(nbits[c]) == rn, f"chunk {c} (n={lens[c]}): {nbits[c]} bits vs oracle {rn}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    for c in range(n_chunks):
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        if lens[c] > 0:
+            assert used[c] == o_dec(ref[c][0], ref[c][1])[1], f"chunk {c}"
+    pieces, new_off, new_avail, pos = [], [], [], 0
+    for c, (rb, rn) in enumerate(ref):
+        g = rng.integers(0, 2, int(rng.integers(0, 71))).astype(np.uint8)
+        pieces += [np.unpackbits(rb)[:rn], g]
+        new_off.append(pos)
+        new_avail.append(rn + g.size)
+        pos += rn + g.size
+    packed = np.packbits(np.concatenate(pieces))
+    buf = torch.zeros((packed.size + 47) // 16 * 16, dtype=torch.uint8, device=dev)
+    buf[:packed.size] = torch.from_numpy(packed).to(dev)
+    buf[packed.size:] = 0xA5  # stale memory behind the last stream must not leak into any count
+    dec2, dlens2, used2, status2 = model.decode_batch(buf, torch.tensor(new_off, dtype=torch.int64, device=dev),
+                                                      torch.tensor(new_avail, dtype=torch.int32, device=dev), cap)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    used2, dec2 = used2.cpu().numpy(), dec2.cpu().numpy()
+    for c, (rb, rn) in enumerate(ref):
+        if lens[c] == 0:
+            continue  # quirk Q5
+        assert np.array_equal(dec2[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        stream = np.packbits(np.concatenate([pieces[2 * c], pieces[2 * c + 1]]))
+        assert used2[c] == o_dec(stream, new_avail[c])[1], f"chunk {c}"
+
+
 def _frame_reference(bits):
     """EncodedBlockWriter.write_block on a bit vector (encoded_stream.py:23-46,94-103,150-175), in numpy"""
     n = bits.size
@@ -416,3 +480,41 @@ def test_random_models_fast_paths_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"{name} K={K} M=2^{m_log2} chunk {c}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} chunk {c}"
+
+
+@pytest.mark.parametrize("mode", ["fixed", "order1"])
+def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
+    """1 GiB batches, three times: the tuned arithmetic-coder kernels against the any-parameter kernel word for
+    word (encode) and against the input (decode).  A timing-dependent fault of about 3 wrong words per GiB in an
+    earlier forward writer (64-bit shift with a just-computed amount, see AnsFwdWriter::put) was only visible at
+    this scale; nothing smaller would have caught it."""
+    n_chunks, chunk_len = 262144, 4096
+    if mode == "fixed":
+        freq = bench_data.t256_table()
+        sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
+        model = models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32)
+    else:
+        base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(256)])
+        sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 256, 1).contiguous()
+        model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
+    assert model.fast_path(chunk_len)
+    pad = torch.zeros((n_chunks, chunk_len + 8), dtype=torch.uint8, device=dev)
+    pad[:, :chunk_len] = sym  # a row stride that is not a multiple of 16 selects the any-parameter kernel
+    ref = model.encode_batch(pad[:, :chunk_len])
+    torch.cuda.synchronize()
+    del pad
+    stride = ref.stride
+    nwords = int((ref.nbits.max().item() + 31) // 32)
+    b = ref.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
+    full = (ref.nbits.to(torch.int64)[:, None] // 32)
+    col = torch.arange(nwords, device=dev)[None, :]
+    del ref
+    for rep in range(3):
+        enc = model.encode_batch(sym)
+        dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+        torch.cuda.synchronize()
+        assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+        a = enc.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
+        assert int(((a != b) & (col < full)).sum()) == 0, f"rep {rep}: stream words differ from the any-parameter kernel"
+        assert torch.equal(dec[:, :chunk_len], sym), f"rep {rep}: decode"
+        del enc, dec, a

@@ -1,0 +1,43 @@
+"""Stress the arithmetic-coder fast kernels at full occupancy: N full-size encodes compared word for word with the
+any-parameter kernel's streams, and every decode compared with the input (rare, timing-dependent faults -- see the
+note in AnsFwdWriter::put -- only show up at this scale).  MODEL=fixed|order1, NCHUNKS, REPS."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from stanford_compression_library_amd import bench_data
+from stanford_compression_library_amd.backend import models
+dev = torch.device("cuda:0")
+n_chunks, chunk_len = int(os.environ.get("NCHUNKS", 262144)), 4096
+mode = os.environ.get("MODEL", "fixed")
+if mode == "fixed":
+    freq = bench_data.t256_table()
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
+    model = models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32)
+else:
+    base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(512)])
+    sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 512, 1).contiguous()
+    model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
+assert model.fast_path(chunk_len)
+# reference streams from the any-parameter kernel: a row stride that is not a multiple of 16 keeps the tuned one out
+pad = torch.zeros((n_chunks, chunk_len + 8), dtype=torch.uint8, device=dev)
+pad[:, :chunk_len] = sym
+ref = model.encode_batch(pad[:, :chunk_len])
+torch.cuda.synchronize()
+stride = ref.stride
+nwords = int((ref.nbits.max().item() + 31) // 32)
+total_bad = total_dec = 0
+for rep in range(int(os.environ.get("REPS", 10))):
+    enc = model.encode_batch(sym)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert torch.equal(enc.nbits, ref.nbits)
+    a = enc.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
+    b = ref.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
+    col = torch.arange(a.shape[1], device=dev)[None, :]
+    nbad = int(((a != b) & (col < (ref.nbits.to(torch.int64)[:, None] // 32))).sum())
+    ndec = int((dec[:, :chunk_len] != sym).any(dim=1).sum())
+    total_bad += nbad
+    total_dec += ndec
+    print("rep", rep, "wrong stream words:", nbad, " chunks decoded wrong:", ndec, flush=True)
+    del enc, dec, a, b
+print(f"TOTAL {mode}: wrong stream words {total_bad}, chunks decoded wrong {total_dec}")
