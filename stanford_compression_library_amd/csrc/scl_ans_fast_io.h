@@ -323,7 +323,7 @@ struct AnsFwdWriter {
             const u32 r = tot - 32;  // <= 31
             // 32-bit arithmetic on purpose.  The obvious (u32)(t >> r) on a 64-bit t compiled to v_lshrrev_b64 with
             // a just-computed VGPR shift amount and, at full occupancy, stored a wrong word about once in 10^8
-            // (tools/stress_aec_static.py: ~3 words per 1 GiB encode held the bits accumulated BEFORE this call);
+            // (tools/stress_fast_kernels.py: ~3 words per 1 GiB encode held the bits accumulated BEFORE this call);
             // this form has been stress-tested clean.  w - r = 32 - nacc is in [1, 32); r == 0 means w == 32 - nacc.
             const u32 word = (r == 0) ? ((hi << (w & 31)) | v) : ((hi << (w - r)) | (v >> r));
             *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32(word);
