@@ -470,6 +470,12 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess && model_kind == SCL_MODEL_IID && K > 16) {
+        u32 init[136];
+        aec_iid_build_init(freq, K, init);
+        e = hipMalloc((void **)&m->d_iid_init, sizeof(init));
+        if (e == hipSuccess) e = hipMemcpy(m->d_iid_init, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         scl_set_error("aec_model_create: device table upload failed: %s", hipGetErrorString(e));
         scl_aec_model_destroy(m);
@@ -485,6 +491,7 @@ extern "C" void scl_aec_model_destroy(scl_aec_model *m) {
     if (!m) return;
     if (m->d_freq) (void)hipFree(m->d_freq);
     if (m->d_cum) (void)hipFree(m->d_cum);
+    if (m->d_iid_init) (void)hipFree(m->d_iid_init);
     delete m;
 }
 
@@ -502,7 +509,7 @@ extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chu
 }
 
 extern "C" int scl_aec_fast_path(const scl_aec_model *m, uint64_t max_symbols) {
-    return (m && (aec_fast_ok(m, max_symbols) || aec_static_ok(m))) ? 1 : 0;
+    return (m && (aec_fast_ok(m, max_symbols) || aec_static_ok(m) || aec_iid_ok(m, max_symbols))) ? 1 : 0;
 }
 
 // per-lane context tables in LDS: at most 256 cells, counts (initial + one per symbol) must fit 16 bits
@@ -538,6 +545,14 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
         aec_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                                d_out_nbits, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
+    // adaptive i.i.d. model on a large alphabet: two-level cumulative table per lane in LDS (scl_aec_iid.hip)
+    if (aec_iid_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
+        sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
+        aec_iid_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                              d_out_nbits, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
@@ -581,6 +596,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
         (out_stride & 15) == 0 && out_stride >= scl_round_up(out_cap, 16)) {
         aec_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                out_cap, d_out_lens, d_consumed, d_status, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
+    if (aec_iid_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
+        out_stride >= scl_round_up(out_cap, 4)) {
+        aec_iid_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                              out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }

@@ -1,0 +1,396 @@
+// scl_aec_iid.hip -- adaptive i.i.d. arithmetic coding (AdaptiveIIDFreqModel) for alphabets up to 256 symbols
+// with the lane's whole model in LDS, one wavefront lane per chunk.  Same streams, bit for bit, as scl_aec.hip
+// and the reference:
+//   ArithmeticEncoder / ArithmeticDecoder   scl/compressors/arithmetic_coding.py:58-161, :177-287
+//   AdaptiveIIDFreqModel                     scl/compressors/probability_models.py:70-92
+//
+// Served models (aec_iid_ok): kind IID, alphabet 17..256 (smaller ones are a single row of scl_aec_fast.hip),
+// PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, initial total + chunk length < 2^15 and below the model's rescale
+// threshold (so the halving rule :86-92 cannot fire inside a chunk).
+//
+// Model layout: two levels of cumulative counts, all u16, 32-byte rows [row][thread] in LDS:
+//   XB[16]      exclusive cumulative totals of the 16 blocks of 16 symbols   (XB[b] = count of all symbols < 16 b)
+//   IC[b][16]   inclusive cumulative counts inside block b                   (IC[b][w] = sum of block b up to w)
+// c[s] = XB[b] + IC[b][w-1], c[s] + f[s] = XB[b] + IC[b][w]  (b = s >> 4, w = s & 15): three 2-byte reads;
+// count[s] += 1 is IC[b][j] += 1 for j >= w and XB[j] += 1 for j > b: sixteen v_pk_add_u16 with two mask rows;
+// the decoder's search is two packed compare-and-counts (block, then symbol) with one dependent row read between.
+// 17 rows x 32 B x 256 lanes = 136 KiB: one workgroup per CU, one wave per SIMD, like scl_aec_fast.hip, whose
+// arithmetic (exact binary64 division, closed-form renormalisation) and per-lane I/O are reused unchanged.
+// The generic kernel scans the 256 counts twice per symbol: 0.38 GB/s round trip on bytes.
+#include "scl_aec_internal.h"
+#include "scl_aec_math.h"
+#include "scl_aec_lane_io.h"
+
+#define AI_THREADS 256
+#define AI_ROW_BYTES (AI_THREADS * 32)          // one 32-byte row of every thread
+#define AI_IC_BASE AI_ROW_BYTES                 // XB row first, then 16 block rows
+#define AI_LUT_GE_BASE (17 * AI_ROW_BYTES)      // mask rows (j >= w)
+#define AI_LUT_GT_BASE (AI_LUT_GE_BASE + 512)   // mask rows (j > b)
+#define AI_LDS_BYTES (AI_LUT_GT_BASE + 512)
+
+struct AecIidDev {
+    u32 K, total0;
+    const u32 *d_init;  // 17 rows x 8 packed u32: XB, then IC[0..15], built from the initial frequencies
+};
+
+struct AiRow {
+    uint4 a, b;
+};
+__device__ __forceinline__ AiRow ai_row_add(const AiRow &R, const uint4 &ia, const uint4 &ib) {
+    AiRow o;
+    o.a = make_uint4(af_pk_add(R.a.x, ia.x), af_pk_add(R.a.y, ia.y), af_pk_add(R.a.z, ia.z), af_pk_add(R.a.w, ia.w));
+    o.b = make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
+    return o;
+}
+// number of the 16 packed u16 of R that are > t  (all values < 2^15), as a positive count
+__device__ __forceinline__ u32 ai_count_gt(const AiRow &R, u32 t) {
+    const u32 tp = t | (t << 16);
+    u32 a0 = 0, a1 = 0;
+    a0 = af_pk_count_gt(a0, tp, R.a.x);
+    a1 = af_pk_count_gt(a1, tp, R.a.y);
+    a0 = af_pk_count_gt(a0, tp, R.a.z);
+    a1 = af_pk_count_gt(a1, tp, R.a.w);
+    a0 = af_pk_count_gt(a0, tp, R.b.x);
+    a1 = af_pk_count_gt(a1, tp, R.b.y);
+    a0 = af_pk_count_gt(a0, tp, R.b.z);
+    a1 = af_pk_count_gt(a1, tp, R.b.w);
+    const u32 acc = af_pk_add(a0, a1);
+    return 0u - ((u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16));
+}
+
+__device__ __forceinline__ void ai_setup_tables(char *lds, const AecIidDev &P, u32 tid) {
+    if (tid < 128) {  // mask rows, register r of a row holds elements 2r and 2r+1
+        const u32 s = tid >> 3, r = tid & 7;
+        const u32 ge = ((2 * r >= s) ? 1u : 0u) | ((2 * r + 1 >= s) ? 0x10000u : 0u);
+        const u32 gt = ((2 * r > s) ? 1u : 0u) | ((2 * r + 1 > s) ? 0x10000u : 0u);
+        *reinterpret_cast<u32_lds *>(lds + AI_LUT_GE_BASE + s * 32 + r * 4) = ge;
+        *reinterpret_cast<u32_lds *>(lds + AI_LUT_GT_BASE + s * 32 + r * 4) = gt;
+    }
+    const uint4 *init = reinterpret_cast<const uint4 *>(P.d_init);
+    for (u32 row = 0; row < 17; ++row) {
+        *reinterpret_cast<uint4_lds *>(lds + row * AI_ROW_BYTES + tid * 32) = init[2 * row];
+        *reinterpret_cast<uint4_lds *>(lds + row * AI_ROW_BYTES + tid * 32 + 16) = init[2 * row + 1];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(AI_THREADS)
+    aec_iid_encode_kernel(AecIidDev P, const u8 *__restrict__ sym, u64 sym_stride, const u32 *__restrict__ lens,
+                          u32 chunk_len, u64 n_chunks, u8 *__restrict__ out, u64 out_stride,
+                          u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits, u32 *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) char lds[AI_LDS_BYTES];
+    const u32 tid = threadIdx.x;
+    ai_setup_tables(lds, P, tid);
+    const u64 chunk = (u64)blockIdx.x * AI_THREADS + tid;
+    if (chunk >= n_chunks) return;
+    const u32 n = lens ? lens[chunk] : chunk_len;
+    const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
+    AfWriter wr;
+    wr.init(out + chunk * out_stride);
+    wr.put(n, 32);
+    u32 st = 0;
+    u32 low = 0, hm = 0xFFFFFFFFu, pending = 0;
+    u32 T = P.total0;  // the total of an i.i.d. model is its initial total plus the symbols seen
+    u32 nextw = 0;
+    const u32 last_word = n ? (n - 1) >> 2 : 0;
+    u32 c_nx = 0, d_nx = 1, T_nx = 1;
+    double x_nx = 1.0;
+    AiRow XB;  // the block-level row also lives in registers (one context: it is never re-read)
+    XB.a = *reinterpret_cast<const uint4_lds *>(lds + tid * 32);
+    XB.b = *reinterpret_cast<const uint4_lds *>(lds + tid * 32 + 16);
+
+    u32 m_rowaddr = 0, m_xb = 0, m_ic = 0, m_icm1 = 0, m_w = 0;
+    AiRow m_IC;
+    uint4 m_ge_a, m_ge_b, m_gt_a, m_gt_b;
+    // model stage, split as in scl_aec_fast.hip: loads first, update and 1/T after the previous symbol is coded
+    auto model_issue = [&](u32 s) {
+        const u32 b = s >> 4, w = s & 15u;
+        m_w = w;
+        m_rowaddr = AI_IC_BASE + b * AI_ROW_BYTES + tid * 32;
+        m_xb = *reinterpret_cast<const u16_lds *>(lds + tid * 32 + 2 * b);
+        m_ic = *reinterpret_cast<const u16_lds *>(lds + m_rowaddr + 2 * w);
+        m_icm1 = *reinterpret_cast<const u16_lds *>(lds + m_rowaddr + 2 * w - 2);  // unused when w == 0
+        m_IC.a = *reinterpret_cast<const uint4_lds *>(lds + m_rowaddr);
+        m_IC.b = *reinterpret_cast<const uint4_lds *>(lds + m_rowaddr + 16);
+        m_ge_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32);
+        m_ge_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32 + 16);
+        m_gt_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32);
+        m_gt_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32 + 16);
+    };
+    auto model_finish = [&]() {
+        c_nx = m_xb + (m_w ? m_icm1 : 0u);
+        d_nx = m_xb + m_ic;
+        T_nx = T;
+        x_nx = af_recip((double)T);
+        // update_model (:83-85): count[s] += 1
+        const AiRow IC2 = ai_row_add(m_IC, m_ge_a, m_ge_b);
+        *reinterpret_cast<uint4_lds *>(lds + m_rowaddr) = IC2.a;
+        *reinterpret_cast<uint4_lds *>(lds + m_rowaddr + 16) = IC2.b;
+        XB = ai_row_add(XB, m_gt_a, m_gt_b);
+        *reinterpret_cast<uint4_lds *>(lds + tid * 32) = XB.a;
+        *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
+        T += 1;
+    };
+    auto code = [&](u32 cc, u32 dd, u32 TT, double xx) {
+        af_shrink(low, hm, cc, dd, TT, xx);
+        u32 k, m;
+        const bool edge = af_renorm_counts(low, hm, k, m);
+        if (__builtin_expect(edge || (k + pending > 32), 0)) {
+            u64 lo = low, hi = (u64)hm + 1;
+            while (hi < AF_HALF || lo > AF_HALF) {
+                if (hi < AF_HALF) {
+                    wr.put(0, 1);
+                    wr.put_run(1, pending);
+                    lo <<= 1;
+                    hi <<= 1;
+                } else {
+                    wr.put(1, 1);
+                    wr.put_run(0, pending);
+                    lo = (lo - AF_HALF) << 1;
+                    hi = (hi - AF_HALF) << 1;
+                }
+                pending = 0;
+            }
+            while (lo > AF_QTR && hi < 3ull * AF_QTR) {
+                pending += 1;
+                lo = (lo - AF_QTR) << 1;
+                hi = (hi - AF_QTR) << 1;
+            }
+            low = (u32)lo;
+            hm = (u32)(hi - 1);
+        } else {
+            if (k > 0) {
+                const u32 top = low >> (32 - k);
+                const u32 b0 = top >> (k - 1);
+                const u32 rest = top & ((1u << (k - 1)) - 1u);
+                const u32 pat = (1u << pending) - (b0 ^ 1u);  // pending <= 31 here
+                wr.put((pat << (k - 1)) | rest, k + pending);
+                pending = 0;
+            }
+            pending += m;
+            const u32 kt = k + m;  // <= 31
+            low = (low << kt) & 0x7FFFFFFFu;
+            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+        }
+    };
+
+    // (c, d, T, 1/T) = (0, 1, 1, 1.0) before the first symbol makes `code` a no-op, see scl_aec_fast.hip
+    const u32 n_words = (n + 3) >> 2;
+    if (n > 0) nextw = src[0];
+    for (u32 w = 0; w < n_words; ++w) {
+        u32 word = nextw;
+        nextw = src[min(w + 1, last_word)];  // unconditional, one word ahead
+        const u32 cnt = min(4u, n - 4 * w);
+#pragma unroll 1
+        for (u32 j = 0; j < cnt; ++j) {
+            u32 s = word & 0xFFu;
+            word >>= 8;
+            if (s >= P.K) {
+                st |= SCL_ST_SYMBOL;
+                s = 0;
+            }
+            const u32 cc = c_nx, dd = d_nx, TT = T_nx;
+            const double xx = x_nx;
+            model_issue(s);
+            code(cc, dd, TT, xx);
+            model_finish();
+        }
+    }
+    code(c_nx, d_nx, T_nx, x_nx);
+    pending += 1;  // termination, :153-159
+    if (low <= AF_QTR) {
+        wr.put(0, 1);
+        wr.put_run(1, pending);
+    } else {
+        wr.put(1, 1);
+        wr.put_run(0, pending);
+    }
+    const u64 total = wr.finish();
+    out_bit_off[chunk] = chunk * out_stride * 8;
+    out_nbits[chunk] = (u32)total;
+    if (status) status[chunk] = st;
+}
+
+__global__ void __launch_bounds__(AI_THREADS)
+    aec_iid_decode_kernel(AecIidDev P, const u8 *__restrict__ in, u64 in_size_bytes, const u64 *__restrict__ bit_off,
+                          const u32 *__restrict__ in_nbits, u64 n_chunks, u8 *__restrict__ out_sym, u64 out_stride,
+                          u32 out_cap, u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
+                          u32 *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) char lds[AI_LDS_BYTES];
+    const u32 tid = threadIdx.x;
+    ai_setup_tables(lds, P, tid);
+    const u64 chunk = (u64)blockIdx.x * AI_THREADS + tid;
+    if (chunk >= n_chunks) return;
+    const u32 nbits = in_nbits[chunk];
+    u32 st = 0;
+    AfReader rd;
+    rd.init(in, in_size_bytes, bit_off[chunk], nbits);
+    u32 n = rd.get(32);
+    if (nbits < 32) {
+        st |= SCL_ST_TRUNCATED;
+        n = 0;
+    }
+    out_lens[chunk] = n;
+    if (n > out_cap) {
+        st |= SCL_ST_CAPACITY;
+        n = 0;
+    }
+    if (n == 0) {  // quirk Q5, as in scl_aec.hip
+        consumed[chunk] = (st == 0) ? 32 + 2 : 0;
+        if (status) status[chunk] = st;
+        return;
+    }
+    u32 *dst = reinterpret_cast<u32 *>(out_sym + chunk * out_stride);
+    u64 used = 32;
+    u32 state = rd.get(32);
+    u32 low = 0, hm = 0xFFFFFFFFu;
+    u32 T = P.total0;
+    AiRow XB;
+    XB.a = *reinterpret_cast<const uint4_lds *>(lds + tid * 32);
+    XB.b = *reinterpret_cast<const uint4_lds *>(lds + tid * 32 + 16);
+    const u32 last_block = (P.K - 1) >> 4;
+    u32 oword = 0;
+    for (u32 i = 0;; ++i) {
+        // ---- decode_step_core, :177-201 ----
+        const double xT = af_recip((double)T);
+        const double xr = af_recip((double)(hm - low) + 1.0);
+        const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
+        u32 tgt = (u32)(num * xr);  // ((state - low + 1) * T - 1) // rng, see scl_aec.hip
+        tgt = min(tgt, T - 1);
+        // block: largest b with XB[b] <= target  (XB[0] = 0 always counts)
+        const u32 b = min(15u - ai_count_gt(XB, tgt), last_block);
+        const u32 rowaddr = AI_IC_BASE + b * AI_ROW_BYTES + tid * 32;
+        const u32 xb = *reinterpret_cast<const u16_lds *>(lds + tid * 32 + 2 * b);
+        AiRow IC;
+        IC.a = *reinterpret_cast<const uint4_lds *>(lds + rowaddr);
+        IC.b = *reinterpret_cast<const uint4_lds *>(lds + rowaddr + 16);
+        const uint4 gt_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32);
+        const uint4 gt_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32 + 16);
+        // symbol inside the block: number of inclusive sums <= target - XB[b]
+        const u32 t2 = tgt - xb;
+        u32 w = 16u - ai_count_gt(IC, t2);
+        w = min(w, min(15u, P.K - 1 - 16 * b));
+        const u32 s = 16 * b + w;
+        const u32 ic = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w);
+        const u32 icm1 = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w - 2);
+        const uint4 ge_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32);
+        const uint4 ge_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32 + 16);
+        const u32 c = xb + (w ? icm1 : 0u), d = xb + ic;
+        // update_model
+        const AiRow IC2 = ai_row_add(IC, ge_a, ge_b);
+        *reinterpret_cast<uint4_lds *>(lds + rowaddr) = IC2.a;
+        *reinterpret_cast<uint4_lds *>(lds + rowaddr + 16) = IC2.b;
+        XB = ai_row_add(XB, gt_a, gt_b);
+        *reinterpret_cast<uint4_lds *>(lds + tid * 32) = XB.a;
+        *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
+        af_shrink(low, hm, c, d, T, xT);
+        T += 1;
+        // ---- symbol out ----
+        oword |= s << (8 * (i & 3));
+        if ((i & 3) == 3) {
+            dst[i >> 2] = oword;
+            oword = 0;
+        }
+        if (i + 1 == n) break;  // before the renormalisation, :242-243
+        // ---- renormalisation, :245-275 ----
+        u32 k, m;
+        const bool edge = af_renorm_counts(low, hm, k, m);
+        if (__builtin_expect(edge, 0)) {
+            u64 lo = low, hi = (u64)hm + 1, stt = state;
+            while (hi < AF_HALF || lo > AF_HALF) {
+                if (hi < AF_HALF) {
+                    lo <<= 1;
+                    hi <<= 1;
+                    stt <<= 1;
+                } else {
+                    lo = (lo - AF_HALF) << 1;
+                    hi = (hi - AF_HALF) << 1;
+                    stt = (stt - AF_HALF) << 1;
+                }
+                stt += rd.get(1);
+                used++;
+            }
+            while (lo > AF_QTR && hi < 3ull * AF_QTR) {
+                lo = (lo - AF_QTR) << 1;
+                hi = (hi - AF_QTR) << 1;
+                stt = (stt - AF_QTR) << 1;
+                stt += rd.get(1);
+                used++;
+            }
+            low = (u32)lo;
+            hm = (u32)(hi - 1);
+            state = (u32)stt;
+        } else {
+            const u32 kt = k + m;  // <= 31
+            const u32 bits = rd.get(kt);
+            const u32 keep = (state << k) & AF_HALF;
+            state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
+            low = (low << kt) & 0x7FFFFFFFu;
+            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            used += kt;
+        }
+    }
+    if ((n & 3) != 0) dst[(n - 1) >> 2] = oword;  // last, partial word (zero-padded inside the row)
+    // how many of the last PRECISION bits belonged to the encoder (:277-282)
+    const u64 lo = low, hi = (u64)hm + 1;
+    u32 e = 0;
+    for (; e < 32; ++e) {
+        const u64 slo = ((u64)state >> e) << e, shi = slo + (1ull << e);
+        if (slo < lo || shi > hi) break;
+    }
+    if (e == 32) e = 31;
+    consumed[chunk] = (u32)((i64)(used + 32) - ((i64)e - 1));
+    if (status) status[chunk] = st;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+bool aec_iid_ok(const scl_aec_model *m, u64 max_symbols) {
+    const AecDev &d = m->dev;
+    if (d.kind != SCL_MODEL_IID || d.K < 17 || d.K > 256 || d.P != 32 || d.size_bits != 32 || !m->d_iid_init)
+        return false;
+    const u64 total_max = (u64)d.total0 + max_symbols;
+    return total_max < 32768 && total_max < d.max_total;
+}
+
+// 17 rows of 16 u16 (packed in u32 pairs) from the initial frequencies: XB, then IC[0..15]
+void aec_iid_build_init(const u32 *h_freq, u32 K, u32 *out136) {
+    u32 rows[17][16];
+    u32 acc = 0;
+    for (u32 b = 0; b < 16; ++b) {
+        rows[0][b] = acc;
+        u32 in_block = 0;
+        for (u32 w = 0; w < 16; ++w) {
+            const u32 s = 16 * b + w;
+            if (s < K) in_block += h_freq[s];
+            rows[1 + b][w] = in_block;
+        }
+        acc += in_block;
+    }
+    for (u32 r = 0; r < 17; ++r)
+        for (u32 j = 0; j < 8; ++j) out136[r * 8 + j] = rows[r][2 * j] | (rows[r][2 * j + 1] << 16);
+}
+
+static AecIidDev aec_iid_dev(const scl_aec_model *m) {
+    AecIidDev f;
+    f.K = m->dev.K;
+    f.total0 = m->dev.total0;
+    f.d_init = m->d_iid_init;
+    return f;
+}
+
+void aec_iid_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
+                           u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
+                           u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + AI_THREADS - 1) / AI_THREADS);
+    hipLaunchKernelGGL(aec_iid_encode_kernel, dim3(blocks), dim3(AI_THREADS), 0, st, aec_iid_dev(m), d_sym, sym_stride,
+                       d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
+}
+
+void aec_iid_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
+                           const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                           u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
+    const u32 blocks = (u32)((n_chunks + AI_THREADS - 1) / AI_THREADS);
+    hipLaunchKernelGGL(aec_iid_decode_kernel, dim3(blocks), dim3(AI_THREADS), 0, st, aec_iid_dev(m), d_in,
+                       in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                       d_consumed, d_status);
+}

@@ -21,6 +21,7 @@ struct scl_aec_model {
     AecDev dev;
     u32 *d_freq, *d_cum;
     u32 h_freq[256];  // host copy of the initial frequencies (all ones for ORDERK)
+    u32 *d_iid_init;  // IID, alphabet > 16: the two-level cumulative table of scl_aec_iid.hip (17 rows x 8 u32)
 };
 
 // scl_aec_fast.hip
@@ -39,3 +40,12 @@ void aec_static_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_s
 void aec_static_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);
+// scl_aec_iid.hip
+bool aec_iid_ok(const scl_aec_model *m, u64 max_symbols);
+void aec_iid_build_init(const u32 *h_freq, u32 K, u32 *out136);
+void aec_iid_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
+                           u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
+                           u32 *d_status, hipStream_t st);
+void aec_iid_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
+                           const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                           u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);

@@ -1,0 +1,125 @@
+// scl_aec_lane_io.h -- per-lane stream I/O and packed-u16 helpers of the arithmetic-coder kernels that keep a
+// private model per lane in LDS (scl_aec_fast.hip: order-k rows, scl_aec_iid.hip: two-level i.i.d. table).
+// These kernels run one wave per SIMD (LDS-bound occupancy), so few lines are open per CU and plain 4-byte
+// accesses are merged by L2; the high-occupancy kernels use the line-granular I/O of scl_ans_fast_io.h instead.
+// Internal to csrc/.
+#pragma once
+#include "scl_common.h"
+
+#ifndef AF_ABLATE
+#define AF_ABLATE 0  // timing experiments only (tools/ablate_aec.sh); 0 = the product
+#endif
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// LDS rows are read as 2-byte elements and written as 16-byte halves: the accesses must not be reordered by
+// type-based alias analysis
+typedef u16 __attribute__((may_alias)) u16_lds;
+typedef u32 __attribute__((may_alias)) u32_lds;
+typedef uint4 __attribute__((may_alias)) uint4_lds;
+
+__device__ __forceinline__ u32 af_pk_add(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
+// acc += (e > t) ? -1 : 0 per 16-bit half (all values < 2^15)
+__device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
+    s16x2 d = __builtin_bit_cast(s16x2, t) - __builtin_bit_cast(s16x2, e);
+    d = d >> (s16x2)(15);
+    return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, acc) + d));
+}
+
+// ---- forward bit writer: completed big-endian words go straight to the slot (4-byte stores; the stream is a
+// third of the input and L2 merges them -- a register FIFO costs ~50 phi copies per symbol, an LDS ring does not fit)
+struct AfWriter {
+    u32 hi;    // pending bits, right-aligned (the oldest is the most significant), < 32 of them
+    u32 nacc;  // number of pending bits
+    u32 *dst;
+    u32 nwords;
+
+    __device__ __forceinline__ void init(u8 *slot) {
+        hi = 0;
+        nacc = 0;
+        nwords = 0;
+        dst = reinterpret_cast<u32 *>(slot);
+    }
+    __device__ __forceinline__ void put(u32 v, u32 nb) {  // v < 2^nb, nb <= 32
+        // 32-bit arithmetic on purpose: see AnsFwdWriter::put (scl_ans_fast_io.h)
+        const u32 tot = nacc + nb;
+        if (tot >= 32) {
+            const u32 r = tot - 32;  // <= 31; nb - r = 32 - nacc
+            const u32 word = (r == 0) ? ((hi << (nb & 31)) | v) : ((hi << (nb - r)) | (v >> r));
+#if AF_ABLATE == 1
+            nwords++;
+#else
+            dst[nwords++] = __builtin_bswap32(word);
+#endif
+            hi = v & ((1u << r) - 1u);
+            nacc = r;
+        } else {
+            hi = (hi << nb) | v;
+            nacc = tot;
+        }
+    }
+    __device__ __forceinline__ void put_run(u32 bit, u32 count) {
+        while (count >= 32) {
+            put(bit ? 0xFFFFFFFFu : 0u, 32);
+            count -= 32;
+        }
+        if (count) put(bit ? ((1u << count) - 1u) : 0u, count);
+    }
+    __device__ __forceinline__ u64 finish() {
+        const u64 total = (u64)nwords * 32 + nacc;
+        if (nacc) dst[nwords] = __builtin_bswap32(hi << (32 - nacc));
+        return total;
+    }
+};
+
+// ---- forward bit reader: 4-byte loads, one word ahead; bits past the end of the stream read as 0 ---------------
+struct AfReader {
+    const u32 *base;
+    u64 nwords;  // readable 32-bit words
+    u64 wi;      // index of the word held in `ahead`
+    u32 ahead;   // raw (memory-order) word wi
+    u64 win;     // bit window, left-aligned
+    u32 nwin;    // valid bits in win (>= 32 between calls)
+    i64 rem;     // stream bits not yet moved into the window (may go negative)
+
+    // index clamped instead of a conditional load (which would have to be waited for at once); words past the
+    // end of the stream are zeroed by `rem` below whatever was loaded
+    __device__ __forceinline__ u32 load(u64 j) const { return base[min(j, nwords - 1)]; }
+    __device__ __forceinline__ u32 next_word() {
+        u32 v = __builtin_bswap32(ahead);
+        ahead = load(++wi);
+        if (rem < 32) v = (rem <= 0) ? 0u : (v & ~(0xFFFFFFFFu >> rem));
+        rem -= 32;
+        return v;
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 nbits) {
+        base = reinterpret_cast<const u32 *>(in);
+        nwords = in_size_bytes >> 2;
+        wi = bit_off >> 5;
+        ahead = load(wi);
+        const u32 skipb = (u32)bit_off & 31u;
+        rem = (i64)nbits + skipb;
+        const u64 hiw = next_word();
+        const u64 low_ = next_word();
+        win = (hiw << 32) | low_;
+        nwin = 64;
+        if (skipb) {  // drop the bits in front of the stream (>= 33 valid bits remain)
+            win <<= skipb;
+            nwin -= skipb;
+        }
+    }
+    __device__ __forceinline__ u32 get(u32 nb) {  // nb <= 32
+        if (nb == 0) return 0;
+        const u32 v = (u32)(win >> (64 - nb));
+        win <<= nb;
+        nwin -= nb;
+        if (nwin < 32) {
+            win |= (u64)next_word() << (32 - nwin);
+            nwin += 32;
+        }
+        return v;
+    }
+};
+

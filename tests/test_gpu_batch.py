@@ -128,13 +128,14 @@ def test_batch_aec_orderk_vs_oracle(K, k, dev):
 
 
 AEC_FAST_CASES = [("orderk", 16, 1), ("orderk", 4, 1), ("orderk", 2, 1), ("orderk", 3, 2), ("orderk", 2, 3),
-                  ("orderk", 5, 0), ("orderk", 16, 0), ("orderk", 7, 1), ("iid", 2, 0), ("iid", 11, 0), ("iid", 16, 0)]
+                  ("orderk", 5, 0), ("orderk", 16, 0), ("orderk", 7, 1), ("iid", 2, 0), ("iid", 11, 0), ("iid", 16, 0),
+                  ("iid", 17, 0), ("iid", 100, 0), ("iid", 255, 0), ("iid", 256, 0)]
 
 
 @pytest.mark.parametrize("kind,K,k", AEC_FAST_CASES)
 def test_batch_aec_lds_table_kernels_vs_oracle(kind, K, k, dev):
     """scl_aec_fast.hip (configs[3]: per-lane context tables in LDS, closed-form renormalisation, binary64
-    division): 300 ragged chunks (two workgroups), every stream equal to the oracle's; decode from the slots and
+    division) and, for i.i.d. models on more than 16 symbols, scl_aec_iid.hip (two-level cumulative table): 300 ragged chunks (two workgroups), every stream equal to the oracle's; decode from the slots and
     from a bit-adjacent buffer with garbage after every stream.  Power-of-two alphabets start every chunk on the
     reference's strict-comparison corner (low == HALF / QTR exactly), i.e. on the literal-loop fallback."""
     rng = np.random.default_rng(1000 + 17 * K + k)
@@ -482,7 +483,7 @@ def test_random_models_fast_paths_vs_oracle(seed, dev):
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} chunk {c}"
 
 
-@pytest.mark.parametrize("mode", ["fixed", "order1"])
+@pytest.mark.parametrize("mode", ["fixed", "order1", "iid"])
 def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
     """1 GiB batches, three times: the tuned arithmetic-coder kernels against the any-parameter kernel word for
     word (encode) and against the input (decode).  A timing-dependent fault of about 3 wrong words per GiB in an
@@ -493,6 +494,11 @@ def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
         freq = bench_data.t256_table()
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
         model = models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32)
+    elif mode == "iid":
+        n_chunks = 65536
+        freq = bench_data.t256_table()
+        sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5001, device=dev)
+        model = models.AecModel(1, [1] * 256, 256, 0, 1 << 30, 32, 32)
     else:
         base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(256)])
         sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 256, 1).contiguous()

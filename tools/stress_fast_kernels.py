@@ -9,10 +9,11 @@ from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 n_chunks, chunk_len = int(os.environ.get("NCHUNKS", 262144)), 4096
 mode = os.environ.get("MODEL", "fixed")
-if mode in ("fixed", "rans", "tans", "range"):
+if mode in ("fixed", "rans", "tans", "range", "iid"):
     freq = bench_data.t256_table()
     sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
     model = {"fixed": lambda: models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32),
+             "iid": lambda: models.AecModel(1, [1] * 256, 256, 0, 1 << 30, 32, 32),
              "rans": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
              "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
              "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()

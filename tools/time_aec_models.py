@@ -5,7 +5,7 @@ from stanford_compression_library_amd import bench_data
 from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 freq = bench_data.t256_table()
-n_chunks, chunk_len = 16384, 4096
+n_chunks, chunk_len = int(os.environ.get('NCHUNKS', 65536)), 4096
 sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=7, device=dev)
 for name, model in [("iid K=256", models.AecModel(1, [1] * 256, 256, 0, 1 << 30, 32, 32)),
                     ("fixed K=256", models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32))]:
