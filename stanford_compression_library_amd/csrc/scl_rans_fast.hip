@@ -211,8 +211,19 @@ typedef AnsBitReader<RD_THREADS> DecIn;
 // decode one symbol: state update + renormalisation from the 32-bit lookahead `lk` (bits are consumed from
 // its top); returns the first table word (symbol in byte 3) and the number of bits used.
 // ML / CB: compile-time m_log2 and 32 - nsb when non-zero, else the run-time values.
+// With compile-time constants and CB == 3 the state is carried TOP-ALIGNED (X = x << 3, what the renormalising
+// v_alignbit produces anyway): the table offset 8 * (x mod M) is X & (8 * (M - 1)) -- one v_and_or with the table
+// base instead of shift + v_and_or -- and the "x = y >> CB" step disappears: two instructions less per symbol.
 template <int ML_T, int CB_T>
 __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt) {
+    if (ML_T != 0 && CB_T == 3) {
+        const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ML_T) - 1u) << 3)));
+        const u32 xn = __umul24(x >> (ML_T + 3), e.x) + e.y;
+        const u32 cl = (u32)__builtin_clz(xn);
+        x = __builtin_amdgcn_alignbit(xn, lk, 32 - cl);  // top-aligned again (its low 3 bits are look-ahead, ignored)
+        used = cl - 3;
+        return e.x;
+    }
     const u32 ML = ML_T ? (u32)ML_T : ml_rt, CB = ML_T ? (u32)CB_T : cb_rt;
     const uint2 e = *reinterpret_cast<const uint2 *>(tab + ((x << 3) & (((1u << ML) - 1u) << 3)));  // v_and_or with the table base
     x = __umul24(x >> ML, e.x) + e.y;                         // v_mad_u32_u24 reads the low 24 bits (f) of e.x
@@ -279,6 +290,8 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, P.size_bits);
     u32 x = r.get(lds, P.nsb);
+    constexpr u32 XSH = (ML_T != 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
+    x <<= XSH;
     out_lens[c] = n;
     if (n > out_cap) {
         st |= SCL_ST_CAPACITY;
@@ -319,7 +332,7 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     }
     const u32 used_bits = r.consumed();
     if (used_bits > avail) st |= SCL_ST_TRUNCATED;
-    else if (st_header == 0 && x != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
+    else if (st_header == 0 && (x >> XSH) != P.L) st |= SCL_ST_STATE;  // assert state == INITIAL_STATE (rANS.py:295)
     consumed[c] = used_bits;
     if (status) status[c] = st;
 }
