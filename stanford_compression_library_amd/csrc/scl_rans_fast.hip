@@ -269,12 +269,14 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
                                                                      u32 out_cap, u32 *__restrict__ out_lens,
                                                                      u32 *__restrict__ consumed,
                                                                      u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char s_lds[RD_RING_BYTES + 4096 * 8];
-    char *lds = s_lds;
-    const char *tab = s_lds + RD_RING_BYTES;
+    // slot table first: its offsets (< 32 KiB) then need no base added (a DS offset field reaches 64 KiB); the ring
+    // works on addresses relative to its own base, which the DS offset field supplies
+    __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + RD_RING_BYTES];
+    char *lds = s_lds + 4096 * 8;
+    const char *tab = s_lds;
     const u32 M = 1u << P.m_log2;
     for (u32 i = threadIdx.x; i < M; i += RD_THREADS)
-        reinterpret_cast<uint2 *>(s_lds + RD_RING_BYTES)[i] = P.d_dec_tab[i];
+        reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec_tab[i];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RD_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
