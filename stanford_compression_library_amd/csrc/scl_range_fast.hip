@@ -137,6 +137,20 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
     const u32 r = range >> m_log2;
     low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
     range = r * e.y;
+    // normalize in closed form: the loop first releases every leading byte on which low and low + range agree
+    // (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them; it goes on only if
+    // the range left after that is below BOTTOM (the carry-less reset, :136-178) -- rare, and handled by the
+    // literal loop.  range > 0, so the two values differ and nb1 <= 3.
+    const u32 nb1 = (u32)__builtin_clz(low ^ (low + range)) >> 3;
+    const u32 sh = 8 * nb1;
+    const u32 range_s = range << sh;
+    if (__builtin_expect(range_s >= RG_BOTTOM, 1)) {
+        bytes = __builtin_bswap32(low) & ((1u << sh) - 1u);  // the released bytes, first one in the low byte
+        nb = nb1;
+        low <<= sh;
+        range = range_s;
+        return;
+    }
     bytes = 0;
     nb = 0;
 #pragma unroll
@@ -358,6 +372,17 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     range = rr * e.y;
     const u32 lk = r.look();
     u32 nb = 0;
+    // closed form of the common case, see rg_encode_symbol
+    const u32 nb1 = (u32)__builtin_clz(low ^ (low + range)) >> 3;
+    const u32 sh = 8 * nb1;
+    const u32 range_s = range << sh;
+    if (__builtin_expect(range_s >= RG_BOTTOM, 1)) {
+        state = (state << sh) | ((lk >> 1) >> (31 - sh));  // the next nb1 bytes (sh may be 0)
+        low <<= sh;
+        range = range_s;
+        r.advance(lds, sh);
+        return s;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool settled = ((low ^ (low + range)) < RG_TOP);
