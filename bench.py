@@ -81,19 +81,32 @@ def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
 
     if args.coder != "rans":
         return None
+    from concurrent.futures import ThreadPoolExecutor
+
+    # the C oracle runs one chunk per call; ctypes releases the GIL, so one Python thread per host core scales
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
     n_probe = min(128, sym_dev.shape[0])
     sym = sym_dev[:n_probe].cpu().numpy()
     t0 = time.perf_counter()
     streams, nbits = orc.rans_encode_batch(sym, freq)
     orc.rans_decode_batch(streams, nbits, freq, sym.shape[1])
     per_chunk = (time.perf_counter() - t0) / n_probe
-    n = int(max(n_probe, min(sym_dev.shape[0], target_seconds / max(per_chunk, 1e-9))))
+    single_thread = sym.size / (per_chunk * n_probe) / 1e6
+    n = int(max(n_probe, min(sym_dev.shape[0], 65536, cores * target_seconds / max(per_chunk, 1e-9))))
     sym = sym_dev[:n].cpu().numpy()
-    t0 = time.perf_counter()
-    streams, nbits = orc.rans_encode_batch(sym, freq)
-    t1 = time.perf_counter()
-    dec, used = orc.rans_decode_batch(streams, nbits, freq, sym.shape[1])
-    t2 = time.perf_counter()
+    bounds = [n * i // cores for i in range(cores + 1)]
+    parts = [(bounds[i], bounds[i + 1]) for i in range(cores) if bounds[i + 1] > bounds[i]]
+    with ThreadPoolExecutor(max_workers=len(parts)) as pool:
+        t0 = time.perf_counter()
+        enc_parts = list(pool.map(lambda ab: orc.rans_encode_batch(sym[ab[0]:ab[1]], freq), parts))
+        t1 = time.perf_counter()
+        dec_parts = list(pool.map(lambda i: orc.rans_decode_batch(enc_parts[i][0], enc_parts[i][1], freq, sym.shape[1]),
+                                  range(len(parts))))
+        t2 = time.perf_counter()
+    streams = np.concatenate([e[0] for e in enc_parts])
+    nbits = np.concatenate([e[1] for e in enc_parts])
+    dec = np.concatenate([d[0] for d in dec_parts])
+    used = np.concatenate([d[1] for d in dec_parts])
     assert np.array_equal(dec, sym) and np.array_equal(used, nbits)
     # parity by-product: GPU streams of the sampled chunks == oracle streams
     g_nbits = enc.nbits[:n].cpu().numpy().astype(np.uint64)
@@ -108,9 +121,11 @@ def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
             assert np.array_equal(got[lo:lo + nb], np.unpackbits(streams[c])[:nb]), f"chunk {c}: GPU != oracle"
     nbytes = sym.size
     return {
-        "value": round(nbytes / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+        "value": round(nbytes / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": len(parts), "kind": "port",
         "sample": f"{n} chunks x {sym.shape[1]} B of the same batch ({nbytes / 2**20:.1f} MiB), oracle/scl_oracle.c "
-                  f"-O2 single thread, encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode {nbytes / (t2 - t1) / 1e6:.2f} MB/s",
+                  f"-O2, {len(parts)} threads (one per host core), encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode "
+                  f"{nbytes / (t2 - t1) / 1e6:.2f} MB/s aggregate; one thread alone: {single_thread:.2f} MB/s round trip",
+        "single_thread_MBps": round(single_thread, 3),
         "encode_MBps": round(nbytes / (t1 - t0) / 1e6, 3), "decode_MBps": round(nbytes / (t2 - t1) / 1e6, 3),
         "gpu_streams_checked_against_oracle": True,
     }
