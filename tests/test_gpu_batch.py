@@ -310,8 +310,9 @@ def test_compact_dense_and_framed(name, framed, dev):
     make_model, o_enc, _ = CODERS[name]
     freq = bench_data.t256_table()
     model = make_model(freq)
-    lens = np.array([0, 1, 5, 13, 100, 101, 102, 103, 104, 105, 106, 107, 200, 17, 1, 0, 64], dtype=np.int32)
-    sym = bench_data.iid_chunks_host(freq, len(lens), 200, seed=21)
+    lens = np.array([0, 1, 5, 13, 100, 101, 102, 103, 104, 105, 106, 107, 200, 17, 1, 0, 64, 1500, 1499, 777, 1024, 33],
+                    dtype=np.int32)  # long streams take the 16-bytes-per-lane bulk path of cp_copy
+    sym = bench_data.iid_chunks_host(freq, len(lens), 1500, seed=21)
     enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
     dense, offsets = models.compact(enc, framed=framed)
     dense, offsets = dense.cpu().numpy(), offsets.cpu().numpy()
