@@ -88,9 +88,13 @@ struct Entries4 {
 
 // 16 symbols (one 16-byte register) -> 8 merged field pairs.  The table entries of the next four symbols are
 // fetched from LDS while the current four are coded (the state chain is serial, the table reads are not).
-template <bool CHECK_SYM, int MSH_T>
-__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, char *lds, const char *tab,
-                                            u32 msh_rt) {
+// CHECK_SYM: 0 = alphabet of 256 symbols, nothing to check; 1 / 2 = flag bytes above n = K - 1 for n <= 127 /
+// n >= 128 with one SWAR test per four symbols: bit 7 of ((b & 0x7F) + c) says (b & 0x7F) > n (mod 128); OR-ed
+// with b (n <= 127: bytes >= 128 are above n anyway) resp. AND-ed with b (n >= 128: only bytes >= 128 can be).
+// `bad` collects those bits; chk_c = 0x01010101 * (127 - n) resp. 0x01010101 * (255 - n).
+template <int CHECK_SYM, int MSH_T>
+__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, u32 chk_c, char *lds,
+                                            const char *tab, u32 msh_rt) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -98,7 +102,8 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u3
         cur.load(wv[d], tab);
         if (CHECK_SYM) {
             const u32 w = wv[d];
-            bad = max(max(bad, max((w << 4) & 0xFF0u, (w >> 4) & 0xFF0u)), max((w >> 12) & 0xFF0u, (w >> 20) & 0xFF0u));
+            const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
+            bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
         const EncSym s0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt);
         const EncSym s1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt);
@@ -110,7 +115,7 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u3
     }
 }
 
-template <bool CHECK_SYM, int MSH_T>
+template <int CHECK_SYM, int MSH_T>
 __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
@@ -133,9 +138,9 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     o.init(threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L;
     u32 bad = 0;
+    const u32 chk_c = 0x01010101u * ((CHECK_SYM == 2 ? 255u : 127u) - (P.K - 1));  // unused when K = 256
 
-    // One 128-byte line per tile.  The loop body is kept to four 16-symbol blocks and the second half of the
-    // line is rotated down, so the hot loop stays well inside the instruction cache.
+    // One 128-byte line per tile.
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
     Line128 cur, nxt;
@@ -144,24 +149,21 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     for (u32 t = 0; t < n_lines; ++t) {
         // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
         // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
-        if (!CHECK_SYM)
-            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
-        else if (t + 1 < n_lines)  // (register budget of the checking variant)
-            nxt.load(src16 + 8 * (t + 1));
-        // straight-line code for the whole line: an inner loop holding only stores would make the compiler drain
-        // vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
+        nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
         if (!CHECK_SYM) {
+            // straight-line code for the whole line: an inner loop holding only stores would make the compiler
+            // drain vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, lds, tab, msh_rt);
+                rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, chk_c, lds, tab, msh_rt);
                 if (i & 1) o.maybe_flush(lds);  // every 32 symbols: <= 12 new words on top of <= 15 pending
             }
-        } else {  // the symbol check needs the registers the unrolled form would spill: two half-line passes
+        } else {  // the checking variants fit their registers only as two half-line passes (no spill this way)
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, lds, tab, msh_rt);
+                    rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, chk_c, lds, tab, msh_rt);
                     if (i & 1) o.maybe_flush(lds);
                 }
 #pragma unroll
@@ -172,19 +174,19 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
-        rf_encode16<CHECK_SYM, MSH_T>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, lds, tab, msh_rt);
+        rf_encode16<CHECK_SYM, MSH_T>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, chk_c, lds, tab, msh_rt);
         o.maybe_flush(lds);
     }
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
-        if (CHECK_SYM) bad = max(bad, a);
+        if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
         const EncSym s = rf_encode_symbol<MSH_T>(x, a, tab, msh_rt);
         o.put(lds, s.bits, s.k);
         if ((i & 15u) == 15u) o.maybe_flush(lds);
     }
     o.maybe_flush(lds);
     o.put32(lds, x, P.nsb);
-    u32 st = (CHECK_SYM && bad >= (P.K << 4)) ? SCL_ST_SYMBOL : 0u;
+    u32 st = (CHECK_SYM && (bad & 0x80808080u)) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
     o.put32(lds, n, P.size_bits);
     const u64 total = o.finish(lds);
@@ -403,8 +405,10 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
                        d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,  \
                        d_status)
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
-    if (m->fdev.K < 256) {
-        if (msh == 10) RF_LAUNCH_ENC(true, 10); else RF_LAUNCH_ENC(true, 0);
+    if (m->fdev.K <= 128) {
+        if (msh == 10) RF_LAUNCH_ENC(1, 10); else RF_LAUNCH_ENC(1, 0);
+    } else if (m->fdev.K < 256) {
+        if (msh == 10) RF_LAUNCH_ENC(2, 10); else RF_LAUNCH_ENC(2, 0);
     } else {
         if (msh == 10) RF_LAUNCH_ENC(false, 10); else RF_LAUNCH_ENC(false, 0);
     }

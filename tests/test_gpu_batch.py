@@ -525,3 +525,28 @@ def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
         assert int(((a != b) & (col < full)).sum()) == 0, f"rep {rep}: stream words differ from the any-parameter kernel"
         assert torch.equal(dec[:, :chunk_len], sym), f"rep {rep}: decode"
         del enc, dec, a
+
+
+@pytest.mark.parametrize("K", [2, 5, 127, 128, 129, 200, 255])
+def test_symbol_range_check_boundaries(K, dev):
+    """ST_SYMBOL (the reference's KeyError, prob_dist.py:208) from the tuned rANS encoder's four-symbols-at-a-time
+    test: K - 1 is the last valid index, K the first invalid one, wherever it sits in a line, a 16-byte block or the
+    ragged tail; chunks without an invalid symbol stay clean."""
+    f = np.ones(K, dtype=np.int64)
+    f[0] += 4096 - K
+    model = models.RansModel(f.tolist(), 1 << 16, 1, 32)
+    n = 128 * 3 + 16 * 2 + 7
+    rng = np.random.default_rng(K)
+    positions = [0, 1, 2, 3, 63, 127, 128, 255, 383, 384, 399, 400, 415, 416, 422]
+    sym = rng.integers(0, K, (2 * len(positions) + 2, n)).astype(np.uint8)
+    expect = np.zeros(sym.shape[0], dtype=bool)
+    for i, p in enumerate(positions):
+        sym[2 * i, p] = K - 1                    # largest valid symbol: no flag
+        sym[2 * i + 1, p] = K                    # first invalid symbol
+        expect[2 * i + 1] = True
+    sym[-1, 200] = 255
+    expect[-1] = K <= 255
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev))
+    torch.cuda.synchronize()
+    flagged = (enc.status.cpu().numpy() & backend_lib.ST_SYMBOL) != 0
+    assert np.array_equal(flagged, expect), np.nonzero(flagged != expect)

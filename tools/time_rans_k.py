@@ -1,0 +1,25 @@
+"""time the rANS fast kernels on a K < 256 alphabet (the symbol-checking encoder variant)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from stanford_compression_library_amd import bench_data
+from stanford_compression_library_amd.backend import models
+dev = torch.device("cuda:0")
+K = int(os.environ.get("K", 64))
+rng = np.random.default_rng(3)
+w = rng.dirichlet(np.ones(K)); f = np.maximum(1, np.floor(4096 * w)).astype(np.int64); f[np.argmax(f)] += 4096 - f.sum()
+n_chunks, chunk_len = 262144, 4096
+sym = bench_data.iid_chunks_device(f, n_chunks, chunk_len, seed=9, device=dev)
+model = models.RansModel(f.tolist(), 1 << 16, 1, 32)
+enc = model.alloc_encoded(n_chunks, chunk_len, dev); dec = model.alloc_decoded(n_chunks, chunk_len, dev)
+for _ in range(2):
+    model.encode_batch(sym, out=enc); model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec)
+torch.cuda.synchronize()
+e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+te = td = 0
+for _ in range(5):
+    e[0].record(); model.encode_batch(sym, out=enc); e[1].record()
+    model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
+    torch.cuda.synchronize(); te += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
+ok = torch.equal(dec[0][:, :chunk_len], sym)
+print(f"K={K}: encode {te/5:.3f} ms  decode {td/5:.3f} ms  round trip ok={ok}")
