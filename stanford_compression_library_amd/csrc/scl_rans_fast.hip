@@ -60,10 +60,12 @@ struct EncSym {
 // s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the pre-shift of x disappears.
 template <int MSH_T>
 __device__ __forceinline__ EncSym rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt) {
-    const u32 MSH = MSH_T ? (u32)MSH_T : msh_rt;
+    // run-time form: msh_rt = MSH | pre << 8.  Tables so small that m < 32 - nsb would need a negative MSH; they
+    // shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
+    const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
     const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
     const u32 k = (e.w >> 24) - neg;
-    const u32 q = rf_umulhi(x, e.x) >> (MSH - neg);
+    const u32 q = rf_umulhi(MSH_T ? x : (x << (msh_rt >> 8)), e.x) >> (MSH - neg);
     EncSym r;
     r.bits = __builtin_amdgcn_ubfe(x, 0, k);
     r.k = k;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    const u32 msh_rt = P.m_log2 - (32 - P.nsb) + 1;
+    const u32 msh_rt = (P.m_log2 >= 32 - P.nsb) ? P.m_log2 - (32 - P.nsb) + 1 : (1u | ((32 - P.nsb - P.m_log2) << 8));
     EncOut o;
     o.init(threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L;
@@ -357,7 +359,6 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     m->fast = 0;
     if (D.b != 1 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || D.m_log2 < 1) return SCL_OK;
     if ((D.RF & (D.RF - 1)) != 0 || D.RF > (1u << 23) || D.nsb > 30 || D.K < 2) return SCL_OK;
-    if (D.m_log2 < 32 - D.nsb) return SCL_OK;  // the encoder folds the pre-shift of x into the quotient shift
     if (m->max_bits_per_symbol > 12) return SCL_OK;
     const u32 M = (u32)D.M, nsb = D.nsb;
     std::vector<uint4> enc(256);

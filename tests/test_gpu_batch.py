@@ -450,7 +450,7 @@ def _random_pow2_table(rng, K, m_log2):
     return f.astype(np.uint32)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_models_fast_paths_vs_oracle(seed, dev):
     """Differential test of the tuned kernels (rANS / tANS / range fast paths) on random power-of-two tables:
     alphabets 2..256, totals 2^1..2^12, flat to extremely skewed, symbols drawn from the table and -- to hit the
@@ -459,6 +459,9 @@ def test_random_models_fast_paths_vs_oracle(seed, dev):
     rng = np.random.default_rng(9000 + seed)
     K = int(rng.choice([2, 3, 5, 16, 17, 100, 255, 256]))
     m_log2 = int(rng.integers(max(1, int(np.ceil(np.log2(K)))), 13))
+    if seed >= 12:  # small tables: totals 2..128 (m < 32 - NUM_STATE_BITS, the pre-shifted quotient of the encoder)
+        K = int(rng.choice([2, 3, 5, 16, 17]))
+        m_log2 = int(rng.integers(max(1, int(np.ceil(np.log2(K)))), 8))
     f = _random_pow2_table(rng, K, m_log2)
     cap = 640
     lens = np.concatenate([[0, 1, 127, 128, 129, 255, 256, 257, 640], rng.integers(0, cap + 1, 31)]).astype(np.int32)

@@ -6,8 +6,9 @@ from stanford_compression_library_amd import bench_data
 from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 K = int(os.environ.get("K", 64))
+M = int(os.environ.get("M", 4096))
 rng = np.random.default_rng(3)
-w = rng.dirichlet(np.ones(K)); f = np.maximum(1, np.floor(4096 * w)).astype(np.int64); f[np.argmax(f)] += 4096 - f.sum()
+w = rng.dirichlet(np.ones(K)); f = np.maximum(1, np.floor((M - K) * w) + 1).astype(np.int64); f[np.argmax(f)] += M - f.sum()
 n_chunks, chunk_len = 262144, 4096
 sym = bench_data.iid_chunks_device(f, n_chunks, chunk_len, seed=9, device=dev)
 model = models.RansModel(f.tolist(), 1 << 16, 1, 32)
@@ -22,4 +23,4 @@ for _ in range(5):
     model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
     torch.cuda.synchronize(); te += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
 ok = torch.equal(dec[0][:, :chunk_len], sym)
-print(f"K={K}: encode {te/5:.3f} ms  decode {td/5:.3f} ms  round trip ok={ok}")
+print(f"K={K} M={M}: encode {te/5:.3f} ms  decode {td/5:.3f} ms  round trip ok={ok}")
