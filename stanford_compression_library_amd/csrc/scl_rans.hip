@@ -11,7 +11,7 @@
 //   * generic  : any M, NUM_BITS_OUT, RANGE_FACTOR with H < 2^63 (u32 or u64 state, real division,
 //                the reference's while-loops kept as loops).  Used for parameter sets outside the
 //                fast path; correctness first.
-//   * fast     : H < 2^32, M = 2^m <= 2^16, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r (the reference
+//   * fast     : H < 2^31, M = 2^m <= 2^12, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r (the reference
 //                defaults with a power-of-two table, BASELINE.json configs[1]): closed-form shift
 //                count, exact reciprocal division, LDS-resident tables, slot -> symbol LUT decode.
 #include <string.h>

@@ -1,5 +1,5 @@
 // scl_rans_fast.hip -- the gfx950 fast path of batched rANS (BASELINE.json configs[1] / headline):
-// u32 state, M = 2^m (m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r, H < 2^31.
+// u32 state, M = 2^m (1 <= m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31, any alphabet 2..256.
 // Same bit stream as the generic kernels in scl_rans.hip (and as reference rANS.py:186-210 / :270-297);
 // what changes is how a lane spends its instructions:
 //
@@ -11,18 +11,17 @@
 //            with rcp = ceil(2^(nsb+s) / f), s = ceil(log2 f): exact for every x < 2^nsb
 //            (error term x*e/(f*2^(nsb+s+k)) < 2^-(s+k) <= 1/(f*2^k))
 //    x     = xs + c[s] + q*(M - f[s])                     == (xs//f)*M + c + xs%f  (rANS.py:138-147)
-//    Two fields are merged before they touch the 32-bit accumulator; completed big-endian words go
-//    through a 4-register queue and leave as one aligned 16-byte store per lane, back to front.
-//  decode, per symbol (one 4-byte LDS table read, slot -> {sym, f, slot - c}):
+//    Two fields are merged before they touch the 32-bit accumulator; completed big-endian words go to a
+//    per-lane LDS ring and leave as whole 128-byte lines, back to front (AnsBackWriter, scl_ans_fast_io.h).
+//  decode, per symbol (one 8-byte LDS table read, slot -> {f | sym << 24, slot - c}):
 //    x  = (x >> m)*f + (slot - c)                          rans_base_decode_step (rANS.py:234-249)
 //    nb = clz(x) - (32 - nsb);  x = (x << nb) | next nb bits   closed form of expand_state (:251-260),
 //         done as one v_alignbit on a normalised copy.
-//    The lane reads its stream through 16-byte loads into a 4-register queue (one block prefetched) and
-//    writes symbols back to front, 16 per store.
+//    The stream arrives as whole 128-byte lines through a per-lane LDS word ring (AnsBitReader); symbols leave
+//    back to front, 128 per burst of eight 16-byte stores.
 //
-// Input symbols are read 16 bytes per lane per load with the next block prefetched.  Per-lane accesses
-// are 16-byte granules at a 4 KiB lane stride; DESIGN.md discusses what that costs at L2 and the
-// wave-cooperative alternative.
+// Every lane only ever moves whole, aligned 128-byte lines of global memory (input symbols: eight 16-byte loads
+// into registers, next line prefetched); DESIGN.md section 3.1 has the measurements that led there.
 #include <vector>
 
 #include "scl_ans_fast_io.h"
