@@ -112,14 +112,25 @@ class _DeviceModel:
                             torch.empty(n_chunks, dtype=torch.int32, device=device), n_chunks)
 
     def encode_batch(self, sym, lens=None, out_stride: Optional[int] = None, stream=None,
-                     out: Optional[EncodedBatch] = None) -> EncodedBatch:
+                     out: Optional[EncodedBatch] = None, any_parameter_kernels: bool = False) -> EncodedBatch:
         """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks].
-        ``out`` reuses buffers from :meth:`alloc_encoded`."""
+        ``out`` reuses buffers from :meth:`alloc_encoded`.  ``any_parameter_kernels`` (tests, stress tools) keeps
+        the tuned kernels out by handing the library rows that do not start on 16-byte boundaries."""
         import torch
 
         assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
         dev = sym.device
+        if any_parameter_kernels and n_chunks:
+            odd = torch.empty((n_chunks, (chunk_len + 15) // 16 * 16 + 8), dtype=torch.uint8, device=dev)
+            odd[:, :chunk_len] = sym
+            sym = odd[:, :chunk_len]
+        elif n_chunks and (sym.stride(0) % 16 or sym.data_ptr() % 16):
+            # the tuned kernels read whole 16-byte blocks / 128-byte lines: rows that do not start on 16-byte
+            # boundaries would silently get the any-parameter kernels (20-50x slower), so re-lay them out once
+            padded = torch.empty((n_chunks, (chunk_len + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+            padded[:, :chunk_len] = sym
+            sym = padded[:, :chunk_len]
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride)
         assert out.n_chunks == n_chunks
@@ -145,15 +156,19 @@ class _DeviceModel:
                 torch.empty(n_chunks, dtype=torch.int32, device=device),
                 torch.empty(n_chunks, dtype=torch.int32, device=device))
 
-    def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None, out=None):
+    def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None, out=None,
+                     any_parameter_kernels: bool = False):
         """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device.
-        ``out`` reuses buffers from :meth:`alloc_decoded`."""
+        ``out`` reuses buffers from :meth:`alloc_decoded`.  ``any_parameter_kernels`` (tests) keeps the tuned
+        kernels out by giving the output rows a stride that is not a multiple of 16."""
         import torch
 
         assert data.is_cuda and data.dtype == torch.uint8
         n_chunks = int(bit_offset.numel())
         dev = data.device
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
+        if any_parameter_kernels:
+            sym = torch.empty((n_chunks, (int(chunk_cap) + 15) // 16 * 16 + 8), dtype=torch.uint8, device=dev)
         out_stride = sym.stride(0)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         args = [self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,

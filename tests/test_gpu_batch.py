@@ -111,13 +111,16 @@ def test_batch_ragged_vs_oracle(name, dev):
 
 @pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0)])
 def test_batch_aec_orderk_vs_oracle(K, k, dev):
-    """order-k adaptive arithmetic coding, private model per lane (BASELINE.json configs[3] shape)"""
+    """order-k adaptive arithmetic coding with the any-parameter kernels (global-memory / LDS16 / two-level
+    models of scl_aec.hip), private model per lane"""
     n_chunks, n = 12, 700
     sym = np.stack([bench_data.markov1_host(K, n, seed=100 + c) for c in range(n_chunks)])
     model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
-    enc = model.encode_batch(torch.from_numpy(sym).to(dev))
-    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, n)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), any_parameter_kernels=True)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, n, any_parameter_kernels=True)
+    dec_t, _, used_t, status_t = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, n)  # tuned, where they apply
     torch.cuda.synchronize()
+    assert int(status_t.abs().sum()) == 0 and torch.equal(dec_t, dec) and torch.equal(used_t, used)
     assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
     data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
     for c in range(n_chunks):
@@ -508,11 +511,8 @@ def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
         sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 256, 1).contiguous()
         model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
     assert model.fast_path(chunk_len)
-    pad = torch.zeros((n_chunks, chunk_len + 8), dtype=torch.uint8, device=dev)
-    pad[:, :chunk_len] = sym  # a row stride that is not a multiple of 16 selects the any-parameter kernel
-    ref = model.encode_batch(pad[:, :chunk_len])
+    ref = model.encode_batch(sym, any_parameter_kernels=True)
     torch.cuda.synchronize()
-    del pad
     stride = ref.stride
     nwords = int((ref.nbits.max().item() + 31) // 32)
     b = ref.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
