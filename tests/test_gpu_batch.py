@@ -1,6 +1,8 @@
 """GPU parity, part 2: the batched C-ABI entry points (device buffers, one lane per chunk) against the CPU
 oracle on seeded inputs -- ragged and empty chunks, trailing-garbage tolerance, stream compaction (dense and
 EncodedBlockWriter framing) -- and size-independent round-trip properties at BASELINE.json configs[1] size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -453,7 +455,7 @@ def _random_pow2_table(rng, K, m_log2):
     return f.astype(np.uint32)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 20))))
 def test_random_models_fast_paths_vs_oracle(seed, dev):
     """Differential test of the tuned kernels (rANS / tANS / range fast paths) on random power-of-two tables:
     alphabets 2..256, totals 2^1..2^12, flat to extremely skewed, symbols drawn from the table and -- to hit the
@@ -553,3 +555,54 @@ def test_symbol_range_check_boundaries(K, dev):
     torch.cuda.synchronize()
     flagged = (enc.status.cpu().numpy() & backend_lib.ST_SYMBOL) != 0
     assert np.array_equal(flagged, expect), np.nonzero(flagged != expect)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 12))))
+def test_random_arithmetic_models_vs_oracle(seed, dev):
+    """Differential test of the three tuned arithmetic-coder kernel families on random models: static tables
+    (any total up to 2^16), adaptive i.i.d. models with random initial counts (alphabets 2..256) and order-k models
+    (K^k <= 16 contexts); 24 ragged chunks each, streams and consumed-bit counts against the oracle.
+    SCL_RANDOM_SEEDS=300 turns this (and the ANS / range twin above) into a campaign."""
+    rng = np.random.default_rng(40000 + seed)
+    cap = 400
+    lens = np.concatenate([[0, 1, 2, 127, 128, 129, 400], rng.integers(0, cap + 1, 17)]).astype(np.int32)
+    kind = ["fixed", "iid", "orderk"][seed % 3]
+    if kind == "fixed":
+        K = int(rng.integers(2, 257))
+        T = int(rng.integers(K, 65537))
+        f = np.maximum(1, np.floor(rng.dirichlet(np.full(K, float(rng.choice([0.1, 1.0, 10.0])))) * (T - K)).astype(np.int64) + 1)
+        f[np.argmax(f)] += T - f.sum()
+        f = f.astype(np.uint32)
+        model = models.AecModel(0, f.tolist(), K, 0, 1 << 30, 32, 32)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_FIXED, K, f_init=f)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_FIXED, K, f_init=f)
+        p = f / f.sum()
+    elif kind == "iid":
+        K = int(rng.integers(2, 257))
+        f = rng.integers(1, 60, K).astype(np.uint32)
+        model = models.AecModel(1, f.tolist(), K, 0, 1 << 30, 32, 32)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_IID, K, f_init=f)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_IID, K, f_init=f)
+        p = rng.dirichlet(np.full(K, 0.3))
+    else:
+        K, k = [(2, 1), (2, 3), (3, 2), (4, 2), (7, 1), (16, 1), (13, 1), (16, 0), (4, 1)][int(rng.integers(0, 9))]
+        model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=k)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_ORDERK, K, k=k)
+        p = rng.dirichlet(np.full(K, 0.5))
+    assert model.fast_path(cap), kind
+    sym = rng.choice(K, (lens.size, cap), p=p).astype(np.uint8)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0, kind
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    for c in range(lens.size):
+        rb, rn = o_enc(sym[c, :lens[c]])
+        assert int(nbits[c]) == rn, f"{kind} K={K} chunk {c}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{kind} K={K} chunk {c}"
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{kind} K={K} chunk {c}"
+        if lens[c] > 0:
+            assert used[c] == o_dec(rb, rn)[1], f"{kind} K={K} chunk {c}"
