@@ -1,5 +1,6 @@
 // scl_rans_fast.hip -- the gfx950 fast path of batched rANS (BASELINE.json configs[1] / headline):
-// u32 state, M = 2^m (1 <= m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31, any alphabet 2..256.
+// u32 state, any total 2 <= M <= 4096 (a power of two gets shifts and masks, any other total an exact binary64
+// division in the decoder), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31, any alphabet 2..256.
 // Same bit stream as the generic kernels in scl_rans.hip (and as reference rANS.py:186-210 / :270-297);
 // what changes is how a lane spends its instructions:
 //
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    const u32 msh_rt = (P.m_log2 >= 32 - P.nsb) ? P.m_log2 - (32 - P.nsb) + 1 : (1u | ((32 - P.nsb - P.m_log2) << 8));
+    const u32 msh_rt = P.enc_msh;  // MSH | pre << 8, see rans_fast_build_tables
     EncOut o;
     o.init(threadIdx.x, out + (c + 1) * out_stride);
     u32 x = P.L;
@@ -217,9 +218,14 @@ typedef AnsBitReader<RD_THREADS> DecIn;
 // With compile-time constants and CB == 3 the state is carried TOP-ALIGNED (X = x << 3, what the renormalising
 // v_alignbit produces anyway): the table offset 8 * (x mod M) is X & (8 * (M - 1)) -- one v_and_or with the table
 // base instead of shift + v_and_or -- and the "x = y >> CB" step disappears: two instructions less per symbol.
+struct RfGenM {  // run-time constants of the any-total decoder
+    double inv_m;
+    u32 m, l;
+};
 template <int ML_T, int CB_T>
-__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt) {
-    if (ML_T != 0 && CB_T == 3) {
+__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt,
+                                                const RfGenM &rf_gen) {
+    if (ML_T > 0 && CB_T == 3) {
         const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ML_T) - 1u) << 3)));
         const u32 xn = __umul24(x >> (ML_T + 3), e.x) + e.y;
         const u32 cl = (u32)__builtin_clz(xn);
@@ -227,7 +233,24 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
         used = cl - 3;
         return e.x;
     }
-    const u32 ML = ML_T ? (u32)ML_T : ml_rt, CB = ML_T ? (u32)CB_T : cb_rt;
+    if (ML_T < 0) {
+        // any total M <= 4096 (ml_rt carries nothing here; the run-time values come through rf_gen):
+        //   x // M exactly as trunc((x + 0.5) * (1 / M)) in binary64 (x < 2^31, M <= 2^12: the error 2^-20 is far
+        //   below the distance 0.5 / M of (x + 0.5) / M from an integer), slot = x - q M;
+        //   expand_state: L = RANGE_FACTOR * M has NUM_STATE_BITS - 1 bits, so the renormalised state has either
+        //   that width (if it is already >= L) or one bit more: one comparison picks between the two.
+        const u32 qd = (u32)(((double)x + 0.5) * rf_gen.inv_m);
+        const u32 slot = x - qd * rf_gen.m;
+        const uint2 e = *reinterpret_cast<const uint2 *>(tab + slot * 8);
+        const u32 xn = __umul24(qd, e.x) + e.y;
+        const u32 cl = (u32)__builtin_clz(xn);
+        const u32 y = __builtin_amdgcn_alignbit(xn, lk, 32 - cl);
+        const u32 lt = ((y >> (cb_rt + 1)) - rf_gen.l) >> 31;  // 1 iff the narrower candidate is below L
+        x = y >> (cb_rt + 1 - lt);
+        used = cl - cb_rt - 1 + lt;
+        return e.x;
+    }
+    const u32 ML = ML_T > 0 ? (u32)ML_T : ml_rt, CB = ML_T > 0 ? (u32)CB_T : cb_rt;
     const uint2 e = *reinterpret_cast<const uint2 *>(tab + ((x << 3) & (((1u << ML) - 1u) << 3)));  // v_and_or with the table base
     x = __umul24(x >> ML, e.x) + e.y;                         // v_mad_u32_u24 reads the low 24 bits (f) of e.x
     const u32 cl = (u32)__builtin_clz(x);                     // x >= 2^r > 0
@@ -239,7 +262,8 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
 
 // 16 symbols, last first, into one 16-byte register (byte i of the result = symbol i of the block)
 template <int ML_T, int CB_T>
-__device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt) {
+__device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt,
+                                             const RfGenM &rf_gen) {
     u32 ow[4];
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
@@ -248,8 +272,8 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
         for (int h = 0; h < 2; ++h) {
             const u32 lk = r.look();
             u32 ua, ub;
-            const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt);
-            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk << ua, ub, tab, ml_rt, cb_rt);
+            const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt, rf_gen);
+            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk << ua, ub, tab, ml_rt, cb_rt, rf_gen);
             r.advance(lds, ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
             o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
             o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
@@ -277,7 +301,7 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + RD_RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
-    const u32 M = 1u << P.m_log2;
+    const u32 M = P.M;
     for (u32 i = threadIdx.x; i < M; i += RD_THREADS)
         reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec_tab[i];
     __syncthreads();
@@ -295,7 +319,7 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, P.size_bits);
     u32 x = r.get(lds, P.nsb);
-    constexpr u32 XSH = (ML_T != 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
+    constexpr u32 XSH = (ML_T > 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
     x <<= XSH;
     out_lens[c] = n;
     if (n > out_cap) {
@@ -304,20 +328,24 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     }
     const u32 st_header = st;
     const u32 ml_rt = P.m_log2, cb_rt = 32 - P.nsb;
+    RfGenM rf_gen;
+    rf_gen.inv_m = 1.0 / (double)P.M;
+    rf_gen.m = P.M;
+    rf_gen.l = P.L;
     u8 *dst = out_sym + c * out_stride;
 
     // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
         u32 used;
-        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, r.look(), used, tab, ml_rt, cb_rt);
+        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, r.look(), used, tab, ml_rt, cb_rt, rf_gen);
         r.advance(lds, used);
         dst[--i] = (u8)(e >> 24);
         if ((i & 3u) == 0) r.maybe_refill(lds);
     }
     // ... whole 16-byte blocks up to a line boundary ...
     while (i & 127u) {
-        const uint4 v = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
+        const uint4 v = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
@@ -326,7 +354,7 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
     while (i) {
         uint4 a[8];
 #pragma unroll
-        for (int b = 7; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt);
+        for (int b = 7; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 128;
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #if RF_ABLATE == 11
@@ -356,23 +384,41 @@ static u32 ceil_log2_u32(u32 v) {
 int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum) {
     const RansDev &D = m->dev;
     m->fast = 0;
-    if (D.b != 1 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || D.m_log2 < 1) return SCL_OK;
+    // any total 2 <= M <= 4096 (a power of two or not), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31
+    if (D.b != 1 || D.M < 2 || D.M > 4096) return SCL_OK;
     if ((D.RF & (D.RF - 1)) != 0 || D.RF > (1u << 23) || D.nsb > 30 || D.K < 2) return SCL_OK;
-    if (m->max_bits_per_symbol > 12) return SCL_OK;
+    if (m->max_bits_per_symbol > 13) return SCL_OK;
     const u32 M = (u32)D.M, nsb = D.nsb;
+    u32 r = 0;
+    while ((1ull << r) < D.RF) ++r;
+    const u32 mp = ceil_log2_u32(M);
+    if (nsb != r + 1 + mp) return SCL_OK;  // cannot happen: bit_width(2 RF M - 1)
+    // Exact division by f through one 32-bit multiply-high for every symbol and BOTH shift counts k in {k1-1, k1}:
+    //   floor((x >> k) / f) = (x * rcp) >> (E + k),  rcp = ceil(2^E / f),  needs E >= nsb + ceil(log2 f);
+    //   E = C - k1 with C = r + 2 mp + 2 makes E + k = C - [x < thresh] the same for all symbols (k1 + ceil(log2 f)
+    //   <= mp + 1), so the shift after the multiply-high is MSH - [x < thresh] with MSH = C - 32 -- or, when C <= 32,
+    //   MSH = 1 after x was shifted left by pre = 33 - C.  For a power-of-two total this is rcp = ceil(2^(nsb+s)/f).
+    const u32 C = r + 2 * mp + 2;
+    const u32 enc_msh = (C >= 33) ? (C - 32) : (1u | ((33 - C) << 8));
     std::vector<uint4> enc(256);
     std::vector<uint2> dec(M);
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
         const u32 f = h_freq[src], c = h_cum[src];
-        const u64 two_rf_f = 2ull * D.RF * f;                           // max_shrunk_state + 1 (rANS.py:112)
-        const u32 k0 = nsb - scl_bit_width_u64(two_rf_f - 1);           // tANS.py:80-81
-        const u64 thresh = two_rf_f << k0;                              // tANS.py:84 (<= 2^nsb)
-        const u32 sh = ceil_log2_u32(f);
-        const u64 rcp = ((1ull << (nsb + sh)) + f - 1) / f;             // ceil(2^(nsb+sh)/f) <= 2^(nsb+1)+1
+        const u64 a1 = 2ull * D.RF * f;  // max_shrunk_state + 1 (rANS.py:112)
+        // shrink_state (rANS.py:149-161) shifts x in [L, 2L) right by the smallest k with (x >> k) < a1: that is
+        // k_lo for x = L and at most k_lo + 1 for x = 2L - 1, the switch being at thresh = a1 << k_lo
+        u32 k_lo = 0, k_hi = 0;
+        while ((D.L >> k_lo) >= a1) ++k_lo;
+        while (((2 * D.L - 1) >> k_hi) >= a1) ++k_hi;
+        const u64 thresh = a1 << k_lo;
+        const u32 k1 = k_lo + 1;
+        if (k_hi > k1 || thresh > (1ull << 31) || C < k1 + 1) return SCL_OK;
+        const u32 E = C - k1;
+        if (E < nsb + ceil_log2_u32(f) || E > 62) return SCL_OK;  // cannot happen (see above)
+        const u64 rcp = ((1ull << E) + f - 1) / f;
         if (rcp >> 32) return SCL_OK;
-        if (sh + k0 != D.m_log2) return SCL_OK;  // cannot happen (see rf_encode_symbol)
-        enc[s] = make_uint4((u32)rcp, (u32)thresh, c, (M - f) | ((k0 + 1) << 24));
+        enc[s] = make_uint4((u32)rcp, (u32)thresh, c, (M - f) | (k1 << 24));
     }
     for (u32 s = 0; s < D.K; ++s)
         for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = make_uint2(h_freq[s] | (s << 24), j);
@@ -389,6 +435,8 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     m->fdev.size_bits = D.size_bits;
     m->fdev.m_log2 = D.m_log2;
     m->fdev.L = (u32)D.L;
+    m->fdev.M = M;
+    m->fdev.enc_msh = enc_msh;
     m->fdev.d_enc_tab = m->d_enc_tab;
     m->fdev.d_dec_tab = m->d_dec_tab;
     m->fast = 1;
@@ -399,7 +447,7 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    const int msh = (int)m->fdev.m_log2 - (32 - (int)m->fdev.nsb) + 1;
+    const int msh = (m->fdev.enc_msh >> 8) ? 0 : (int)m->fdev.enc_msh;  // literal form only without a pre-shift
 #define RF_LAUNCH_ENC(CHECK, MSH)                                                                              \
     hipLaunchKernelGGL((rans_encode_fast_kernel<CHECK, MSH>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
                        d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,  \
@@ -420,7 +468,11 @@ void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_siz
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RD_THREADS - 1) / RD_THREADS);
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
-    if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29)
+    if (m->fdev.m_log2 == 0xFFFFFFFFu)  // total is not a power of two
+        hipLaunchKernelGGL((rans_decode_fast_kernel<-1, 0>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
+                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status);
+    else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29)
         hipLaunchKernelGGL((rans_decode_fast_kernel<12, 3>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
                            in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                            d_consumed, d_status);

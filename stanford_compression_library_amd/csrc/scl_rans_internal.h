@@ -14,13 +14,15 @@ struct RansDev {
     const u32 *d_cum;
 };
 
-// fast path: H < 2^31, M = 2^m (m <= 12), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r
+// fast path: H < 2^31, 2 <= M <= 4096, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r
 struct RansFastDev {
     u32 K;
     u32 nsb;        // NUM_STATE_BITS = r + m + 1 <= 30
     u32 size_bits;
-    u32 m_log2;
+    u32 m_log2;     // log2(M) if M is a power of two, else 0xFFFFFFFF
     u32 L;
+    u32 M;
+    u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 (rans_fast_build_tables)
     const uint4 *d_enc_tab;  // [256] {rcp, thresh, cum, (M-f) | (k0+1) << 24}
     const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
