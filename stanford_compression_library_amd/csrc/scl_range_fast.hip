@@ -1,7 +1,7 @@
 // scl_range_fast.hip -- gfx950 fast path of the batched 32-bit range coder (BASELINE.json configs[2]).
 //
 // Same byte stream as scl_range.hip / reference scl/compressors/range_coder.py:188-207 (encode) and
-// :269-317 (decode).  Serves PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, total_freq = 2^m <= 4096; every other
+// :269-317 (decode).  Serves PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, any total_freq <= 4096; every other
 // parameter set runs the generic kernels.  Memory access follows the rule established for rANS
 // (scl_rans_fast.hip, profiles/r01_v2 -> r01_v3): a lane only ever moves whole lines / 64-byte sectors.
 //   encode: 128-byte input lines in registers (next line prefetched); emitted bytes are gathered per symbol
@@ -122,6 +122,19 @@ struct RgOut {
     }
 };
 
+// range // M (shrink_range, :100): a shift for a power-of-two total (GEN = false, md.m_log2), else exactly as
+// trunc((range + 0.5) * (1 / M)) in binary64 (range < 2^32, M <= 2^12: the error 2^-20 is far below the distance
+// 0.5 / M of (range + 0.5) / M from an integer)
+struct RgDivM {
+    u32 m_log2;
+    double inv_m;
+};
+template <bool GEN>
+__device__ __forceinline__ u32 rg_range_over_m(u32 range, const RgDivM &md) {
+    if (GEN) return (u32)(((double)range + 0.5) * md.inv_m);
+    return range >> md.m_log2;
+}
+
 __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
     const bool settled = ((low ^ (low + range)) < RG_TOP);
     if (!settled && range >= RG_BOTTOM) return false;
@@ -132,9 +145,10 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
 // shrink_range (:88-105) + normalize (:107-179) for one symbol; returns the first (up to four) released bytes.
 // A symbol releases at most PRECISION/8 = 4 bytes in practice; callers still run rg_needs_byte afterwards so a
 // fifth byte could never be lost.
-__device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, u32 m_log2, u32 &bytes,
+template <bool GEN>
+__device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, const RgDivM &md, u32 &bytes,
                                                  u32 &nb) {
-    const u32 r = range >> m_log2;
+    const u32 r = rg_range_over_m<GEN>(range, md);
     low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
     range = r * e.y;
     // normalize in closed form: the loop first releases every leading byte on which low and low + range agree
@@ -173,8 +187,9 @@ struct RgLine128 {
     }
 };
 
+template <bool GEN>
 __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range, RgOut &o, u32 &bad, char *lds,
-                                            const char *tab, u32 m_log2) {
+                                            const char *tab, const RgDivM &md) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -184,7 +199,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
         for (int j = 0; j < 4; ++j) {
             bad = max(bad, a[j]);
             u32 bytes, nb;
-            rg_encode_symbol(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), m_log2, bytes, nb);
+            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), md, bytes, nb);
             o.put_bytes(lds, bytes, nb);
             while (nb == 4 && rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
                 o.put_bytes(lds, low >> 24, 1);
@@ -196,6 +211,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
     o.maybe_flush(lds);
 }
 
+template <bool GEN>
 __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(RangeFastDev P, const u8 *__restrict__ sym,
                                                                           u64 sym_stride,
                                                                           const u32 *__restrict__ lens, u32 chunk_len,
@@ -216,7 +232,9 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     o.init(threadIdx.x, out + c * out_stride, out_stride);
     o.put_bytes(lds, __builtin_bswap32(n), 4);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
     u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
-    const u32 m_log2 = P.m_log2;
+    RgDivM md;
+    md.m_log2 = P.m_log2;
+    md.inv_m = 1.0 / (double)P.M;
 
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
@@ -227,8 +245,8 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
         if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));
 #pragma nounroll
         for (int q = 0; q < 4; ++q) {
-            rg_encode16(cur.v[0], low, range, o, bad, lds, tab, m_log2);
-            rg_encode16(cur.v[1], low, range, o, bad, lds, tab, m_log2);
+            rg_encode16<GEN>(cur.v[0], low, range, o, bad, lds, tab, md);
+            rg_encode16<GEN>(cur.v[1], low, range, o, bad, lds, tab, md);
 #pragma unroll
             for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
         }
@@ -236,12 +254,12 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16)
-        rg_encode16(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, m_log2);
+        rg_encode16<GEN>(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, md);
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 3;
         bad = max(bad, a);
         u32 bytes, nb;
-        rg_encode_symbol(low, range, *reinterpret_cast<const uint2 *>(tab + a), m_log2, bytes, nb);
+        rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a), md, bytes, nb);
         o.put_bytes(lds, bytes, nb);
         while (nb == 4 && rg_needs_byte(low, range)) {
             o.put_bytes(lds, low >> 24, 1);
@@ -361,9 +379,10 @@ __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
 }
 
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
+template <bool GEN>
 __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
-                                                const u8 *s2s, u32 m_log2, u32 slot_max) {
-    const u32 rr = range >> m_log2;
+                                                const u8 *s2s, const RgDivM &md, u32 slot_max) {
+    const u32 rr = rg_range_over_m<GEN>(range, md);
     u32 q = rg_div(state - low, rr);
     q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
     const u32 s = s2s[q];
@@ -403,6 +422,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     return s;
 }
 
+template <bool GEN>
 __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,
                                                                        const u64 *__restrict__ bit_off,
@@ -415,7 +435,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     char *lds = s_lds;
     const char *tab = s_lds + RGD_RING_BYTES;
     const u8 *s2s = reinterpret_cast<const u8 *>(s_lds + RGD_RING_BYTES + 256 * 8);
-    const u32 M = 1u << P.m_log2;
+    const u32 M = P.M;
     if (threadIdx.x < 256) reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[threadIdx.x] = P.d_enc_tab[threadIdx.x];
     for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) s_lds[RGD_RING_BYTES + 256 * 8 + i] = (char)P.d_slot2sym[i];
     __syncthreads();
@@ -440,7 +460,10 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     }
     u8 *dst = out_sym + c * out_stride;
     u32 low = 0, range = 0xFFFFFFFFu;
-    const u32 m_log2 = P.m_log2, slot_max = M - 1;
+    const u32 slot_max = M - 1;
+    RgDivM md;
+    md.m_log2 = P.m_log2;
+    md.inv_m = 1.0 / (double)P.M;
 
     u32 i = 0;
     // 128 symbols per iteration: eight registers, one burst of eight 16-byte stores (a whole line)
@@ -455,7 +478,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                 u32 o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32 s = rg_decode_symbol(low, range, state, r, lds, tab, s2s, m_log2, slot_max);
+                    const u32 s = rg_decode_symbol<GEN>(low, range, state, r, lds, tab, s2s, md, slot_max);
                     o |= s << (8 * j);
                 }
                 r.maybe_refill(lds);
@@ -469,7 +492,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     for (; i < n; ++i) {  // ragged tail
-        dst[i] = (u8)rg_decode_symbol(low, range, state, r, lds, tab, s2s, m_log2, slot_max);
+        dst[i] = (u8)rg_decode_symbol<GEN>(low, range, state, r, lds, tab, s2s, md, slot_max);
         if ((i & 3u) == 3u) r.maybe_refill(lds);
     }
     const u32 used_bits = r.consumed();
@@ -484,7 +507,8 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
 int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_cum) {
     const RangeDev &D = m->dev;
     m->fast = 0;
-    if (D.P != 32 || D.size_bits != 32 || D.m_log2 == 0xFFFFFFFFu || D.m_log2 > 12 || !m->d_slot2sym) return SCL_OK;
+    // any total up to 4096 (the slot -> symbol table of the decoder sits in LDS)
+    if (D.P != 32 || D.size_bits != 32 || D.M < 1 || D.M > 4096 || !m->d_slot2sym) return SCL_OK;
     std::vector<uint2> tab(256);
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;
@@ -498,6 +522,7 @@ int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_
     }
     m->fdev.K = D.K;
     m->fdev.m_log2 = D.m_log2;
+    m->fdev.M = D.M;
     m->fdev.d_enc_tab = m->d_enc_tab;
     m->fdev.d_slot2sym = m->d_slot2sym;
     m->fast = 1;
@@ -508,15 +533,24 @@ void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym
                               u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                               u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RGE_THREADS - 1) / RGE_THREADS);
-    hipLaunchKernelGGL(range_encode_fast_kernel, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym, sym_stride,
-                       d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+    if (m->fdev.m_log2 != 0xFFFFFFFFu)
+        hipLaunchKernelGGL(range_encode_fast_kernel<false>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+    else
+        hipLaunchKernelGGL(range_encode_fast_kernel<true>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
 }
 
 void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RGD_THREADS - 1) / RGD_THREADS);
-    hipLaunchKernelGGL(range_decode_fast_kernel, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in, in_size_bytes,
-                       d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
-                       d_status);
+    if (m->fdev.m_log2 != 0xFFFFFFFFu)
+        hipLaunchKernelGGL(range_decode_fast_kernel<false>, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in,
+                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status);
+    else
+        hipLaunchKernelGGL(range_decode_fast_kernel<true>, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in,
+                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status);
 }

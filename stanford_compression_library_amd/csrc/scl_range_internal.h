@@ -14,10 +14,11 @@ struct RangeDev {
     const u8 *d_slot2sym;  // [M] slot -> symbol (decode LUT), null when M is too large
 };
 
-// fast path: PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, M = 2^m <= 4096
+// fast path: PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, any total M <= 4096
 struct RangeFastDev {
     u32 K;
-    u32 m_log2;
+    u32 m_log2;  // log2(M) if power of two else 0xFFFFFFFF
+    u32 M;
     const uint2 *d_enc_tab;  // [256] {cum, freq}
     const u8 *d_slot2sym;    // [M]
 };

@@ -609,7 +609,7 @@ def test_random_arithmetic_models_vs_oracle(seed, dev):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 16))))
-def test_random_totals_rans_fast_path_vs_oracle(seed, dev):
+def test_random_totals_fast_paths_vs_oracle(seed, dev):
     """rANS with ANY total 2..4096 (the reference does not ask for a power of two, and its own tests use 5, 30, 92,
     874 ...): the tuned kernels divide by the total exactly in binary64 and pick the renormalised width with one
     comparison.  Random totals, alphabets and RANGE_FACTORs; 40 ragged chunks against the oracle."""
@@ -623,21 +623,25 @@ def test_random_totals_rans_fast_path_vs_oracle(seed, dev):
     f = np.diff(np.concatenate([[0], cuts, [M]])).astype(np.uint32)
     assert f.sum() == M and f.min() >= 1
     rf = int(rng.choice([1 << 16, 1 << 16, 1 << 8, 1 << 12, 1, 2]))
-    model = models.RansModel(f.tolist(), rf, 1, 32)
-    assert model.info().fast_path == 1, (M, rf)
+    rans = models.RansModel(f.tolist(), rf, 1, 32)
+    assert rans.info().fast_path == 1, (M, rf)
     cap = 640
     lens = np.concatenate([[0, 1, 127, 128, 129, 255, 256, 257, 640], rng.integers(0, cap + 1, 31)]).astype(np.int32)
     p = f / f.sum()
     sym = np.stack([rng.choice(K, cap, p=p) if c % 3 else rng.integers(0, K, cap) for c in range(lens.size)]).astype(np.uint8)
-    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
-    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
-    torch.cuda.synchronize()
-    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
-    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
-    dec = dec.cpu().numpy()
-    assert np.array_equal(dlens.cpu().numpy(), lens) and np.array_equal(used.cpu().numpy(), nbits)
-    for c in range(lens.size):
-        rb, rn = orc.rans_encode(sym[c, :lens[c]], f, RF=rf)
-        assert int(nbits[c]) == rn, f"M={M} RF={rf} chunk {c}"
-        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"M={M} chunk {c}"
-        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"M={M} chunk {c}"
+    d_sym, d_lens = torch.from_numpy(sym).to(dev), torch.from_numpy(lens).to(dev)
+    # the range coder's tuned kernels take any total up to 4096 as well (range // M in binary64)
+    for name, model, o_enc in [("rans", rans, lambda s: orc.rans_encode(s, f, RF=rf)),
+                               ("range", models.RangeModel(f.tolist(), 32, 32), lambda s: orc.range_encode(s, f))]:
+        enc = model.encode_batch(d_sym, lens=d_lens)
+        dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+        torch.cuda.synchronize()
+        assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0, name
+        data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+        dec = dec.cpu().numpy()
+        assert np.array_equal(dlens.cpu().numpy(), lens) and np.array_equal(used.cpu().numpy(), nbits), name
+        for c in range(lens.size):
+            rb, rn = o_enc(sym[c, :lens[c]])
+            assert int(nbits[c]) == rn, f"{name} M={M} RF={rf} chunk {c}"
+            assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} M={M} chunk {c}"
+            assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} M={M} chunk {c}"
