@@ -148,6 +148,8 @@ int scl_range_model_create(const uint32_t *h_freq, uint32_t K, uint32_t precisio
                            uint32_t size_bits, scl_range_model **out);
 void scl_range_model_destroy(scl_range_model *m);
 uint64_t scl_range_slot_bytes(const scl_range_model *m, uint64_t n_symbols);
+/* 1 if the tuned kernels serve this model (PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32), 0 if the any-parameter ones do */
+int scl_range_fast_path(const scl_range_model *m);
 int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d_sym, uint64_t sym_stride,
                            const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
                            uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,

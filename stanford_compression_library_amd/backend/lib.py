@@ -68,6 +68,7 @@ _SIGNATURES = {
     "scl_range_model_create": (_int, [_u32p, _u32, _u32, _u32, C.POINTER(_vp)]),
     "scl_range_model_destroy": (None, [_vp]),
     "scl_range_slot_bytes": (_u64, [_vp, _u64]),
+    "scl_range_fast_path": (_int, [_vp]),
     "scl_range_encode_batch": (_int, _ENC_BATCH),
     "scl_range_decode_batch": (_int, _DEC_BATCH),
     "scl_range_encode_host": (_int, _ENC_HOST),

@@ -238,6 +238,10 @@ class RangeModel(_DeviceModel):
         _lib.check(rc, "scl_range_model_create")
         self.size_bits = int(size_bits)
 
+    def fast_path(self) -> bool:
+        """True if the tuned kernels (scl_range_fast.hip) serve this model."""
+        return bool(self._L.scl_range_fast_path(self._h))
+
 
 class AecModel(_DeviceModel):
     _prefix = "aec"

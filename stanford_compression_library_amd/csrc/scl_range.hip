@@ -212,6 +212,8 @@ extern "C" void scl_range_model_destroy(scl_range_model *m) {
     delete m;
 }
 
+extern "C" int scl_range_fast_path(const scl_range_model *m) { return (m && m->fast) ? 1 : 0; }
+
 extern "C" uint64_t scl_range_slot_bytes(const scl_range_model *m, uint64_t n_symbols) {
     if (!m) return 0;
     // a symbol can shift out at most P/8 bytes (range drops from 2^P to >= 1), typically log2(M/f)/8

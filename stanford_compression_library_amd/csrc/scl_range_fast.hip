@@ -1,7 +1,7 @@
 // scl_range_fast.hip -- gfx950 fast path of the batched 32-bit range coder (BASELINE.json configs[2]).
 //
 // Same byte stream as scl_range.hip / reference scl/compressors/range_coder.py:188-207 (encode) and
-// :269-317 (decode).  Serves PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, any total_freq <= 4096; every other
+// :269-317 (decode).  Serves PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, any total_freq the coder allows (<= 2^16); every other
 // parameter set runs the generic kernels.  Memory access follows the rule established for rANS
 // (scl_rans_fast.hip, profiles/r01_v2 -> r01_v3): a lane only ever moves whole lines / 64-byte sectors.
 //   encode: 128-byte input lines in registers (next line prefetched); emitted bytes are gathered per symbol
@@ -127,6 +127,7 @@ struct RgOut {
 // 0.5 / M of (range + 0.5) / M from an integer)
 struct RgDivM {
     u32 m_log2;
+    u32 k;
     double inv_m;
 };
 template <bool GEN>
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
     RgDivM md;
     md.m_log2 = P.m_log2;
+    md.k = P.K;
     md.inv_m = 1.0 / (double)P.M;
 
     const u32 n_lines = n >> 7;
@@ -379,13 +381,26 @@ __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
 }
 
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
-template <bool GEN>
+// LUT: totals up to 4096 find the symbol in a slot -> symbol table; larger ones (up to BOTTOM = 2^16) by an 8-step
+// binary search on the cumulative counts (K = alphabet size rides in md.k)
+template <bool GEN, bool LUT>
 __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
                                                 const u8 *s2s, const RgDivM &md, u32 slot_max) {
     const u32 rr = rg_range_over_m<GEN>(range, md);
     u32 q = rg_div(state - low, rr);
     q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
-    const u32 s = s2s[q];
+    u32 s;
+    if (LUT) {
+        s = s2s[q];
+    } else {
+        s = 0;
+#pragma unroll
+        for (u32 b = 128; b > 0; b >>= 1) {
+            const u32 t = s + b;
+            const u32 ct = *reinterpret_cast<const u32 *>(tab + min(t, 255u) * 8);
+            s = (t < md.k && ct <= q) ? t : s;
+        }
+    }
     const uint2 e = *reinterpret_cast<const uint2 *>(tab + s * 8);
     low += e.x * rr;
     range = rr * e.y;
@@ -422,7 +437,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     return s;
 }
 
-template <bool GEN>
+template <bool GEN, bool LUT>
 __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,
                                                                        const u64 *__restrict__ bit_off,
@@ -437,7 +452,8 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     const u8 *s2s = reinterpret_cast<const u8 *>(s_lds + RGD_RING_BYTES + 256 * 8);
     const u32 M = P.M;
     if (threadIdx.x < 256) reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[threadIdx.x] = P.d_enc_tab[threadIdx.x];
-    for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) s_lds[RGD_RING_BYTES + 256 * 8 + i] = (char)P.d_slot2sym[i];
+    if (LUT)
+        for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) s_lds[RGD_RING_BYTES + 256 * 8 + i] = (char)P.d_slot2sym[i];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RGD_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -463,6 +479,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     const u32 slot_max = M - 1;
     RgDivM md;
     md.m_log2 = P.m_log2;
+    md.k = P.K;
     md.inv_m = 1.0 / (double)P.M;
 
     u32 i = 0;
@@ -478,7 +495,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                 u32 o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32 s = rg_decode_symbol<GEN>(low, range, state, r, lds, tab, s2s, md, slot_max);
+                    const u32 s = rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, s2s, md, slot_max);
                     o |= s << (8 * j);
                 }
                 r.maybe_refill(lds);
@@ -492,7 +509,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     for (; i < n; ++i) {  // ragged tail
-        dst[i] = (u8)rg_decode_symbol<GEN>(low, range, state, r, lds, tab, s2s, md, slot_max);
+        dst[i] = (u8)rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, s2s, md, slot_max);
         if ((i & 3u) == 3u) r.maybe_refill(lds);
     }
     const u32 used_bits = r.consumed();
@@ -507,8 +524,9 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
 int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_cum) {
     const RangeDev &D = m->dev;
     m->fast = 0;
-    // any total up to 4096 (the slot -> symbol table of the decoder sits in LDS)
-    if (D.P != 32 || D.size_bits != 32 || D.M < 1 || D.M > 4096 || !m->d_slot2sym) return SCL_OK;
+    // any total the coder allows (M <= BOTTOM = 2^16, range_coder.py:85); the decoder's slot -> symbol table sits in
+    // LDS for totals up to 4096, larger ones search the cumulative counts
+    if (D.P != 32 || D.size_bits != 32 || D.M < 1 || D.M > 65536 || !m->d_slot2sym) return SCL_OK;
     std::vector<uint2> tab(256);
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;
@@ -545,12 +563,14 @@ void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_s
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RGD_THREADS - 1) / RGD_THREADS);
-    if (m->fdev.m_log2 != 0xFFFFFFFFu)
-        hipLaunchKernelGGL(range_decode_fast_kernel<false>, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in,
-                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status);
-    else
-        hipLaunchKernelGGL(range_decode_fast_kernel<true>, dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in,
-                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status);
+#define RG_LAUNCH_DEC(GEN, LUT)                                                                                  \
+    hipLaunchKernelGGL((range_decode_fast_kernel<GEN, LUT>), dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in, \
+                       in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,   \
+                       d_consumed, d_status)
+    const bool pow2 = m->fdev.m_log2 != 0xFFFFFFFFu, lut = m->fdev.M <= 4096;
+    if (pow2 && lut) RG_LAUNCH_DEC(false, true);
+    else if (pow2) RG_LAUNCH_DEC(false, false);
+    else if (lut) RG_LAUNCH_DEC(true, true);
+    else RG_LAUNCH_DEC(true, false);
+#undef RG_LAUNCH_DEC
 }

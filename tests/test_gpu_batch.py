@@ -645,3 +645,39 @@ def test_random_totals_fast_paths_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"{name} M={M} RF={rf} chunk {c}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} M={M} chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} M={M} chunk {c}"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 10))))
+def test_range_coder_large_totals_vs_oracle(seed, dev):
+    """Range coder with totals above 4096 and up to BOTTOM = 2^16 (the reference's own extreme tables are {1, 65535}
+    and {1, 1, 65534}, range_coder.py:336-374): the tuned decoder finds the symbol by binary search on the
+    cumulative counts.  30 ragged chunks against the oracle."""
+    rng = np.random.default_rng(81000 + seed)
+    if seed == 0:
+        f = np.array([1, 65535], dtype=np.uint32)
+    elif seed == 1:
+        f = np.array([1, 1, 65534], dtype=np.uint32)
+    else:
+        K = int(rng.choice([2, 5, 17, 100, 256]))
+        M = int(rng.integers(4097, 65537))
+        cuts = np.sort(rng.choice(np.arange(1, M), K - 1, replace=False))
+        f = np.diff(np.concatenate([[0], cuts, [M]])).astype(np.uint32)
+    K = f.size
+    model = models.RangeModel(f.tolist(), 32, 32)
+    assert model.fast_path()
+    cap = 520
+    lens = np.concatenate([[0, 1, 2, 127, 128, 129, 520], rng.integers(0, cap + 1, 23)]).astype(np.int32)
+    p = f / f.sum()
+    sym = np.stack([rng.choice(K, cap, p=p) if c % 3 else rng.integers(0, K, cap) for c in range(lens.size)]).astype(np.uint8)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec = dec.cpu().numpy()
+    assert np.array_equal(dlens.cpu().numpy(), lens) and np.array_equal(used.cpu().numpy(), nbits)
+    for c in range(lens.size):
+        rb, rn = orc.range_encode(sym[c, :lens[c]], f)
+        assert int(nbits[c]) == rn, f"chunk {c}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
