@@ -492,10 +492,10 @@ def test_random_models_fast_paths_vs_oracle(seed, dev):
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} chunk {c}"
 
 
-@pytest.mark.parametrize("mode", ["fixed", "order1", "iid"])
-def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
-    """1 GiB batches, three times: the tuned arithmetic-coder kernels against the any-parameter kernel word for
-    word (encode) and against the input (decode).  A timing-dependent fault of about 3 wrong words per GiB in an
+@pytest.mark.parametrize("mode", ["fixed", "order1", "iid", "rans", "tans", "range", "rans_total_3000"])
+def test_tuned_kernels_full_occupancy_stress(mode, dev):
+    """1 GiB batches, three times: every tuned kernel family against the any-parameter kernels word for word
+    (encode) and against the input (decode).  A timing-dependent fault of about 3 wrong words per GiB in an
     earlier forward writer (64-bit shift with a just-computed amount, see AnsFwdWriter::put) was only visible at
     this scale; nothing smaller would have caught it."""
     n_chunks, chunk_len = 262144, 4096
@@ -503,6 +503,16 @@ def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
         freq = bench_data.t256_table()
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
         model = models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32)
+    elif mode in ("rans", "tans", "range", "rans_total_3000"):
+        freq = bench_data.t256_table()
+        if mode == "rans_total_3000":  # a total that is not a power of two: the binary64 division of the decoder
+            freq = np.maximum(1, (freq.astype(np.int64) * 3000) // 4096)
+            freq[np.argmax(freq)] += 3000 - freq.sum()
+        sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5002, device=dev)
+        model = {"rans": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+                 "rans_total_3000": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+                 "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
+                 "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
     elif mode == "iid":
         n_chunks = 65536
         freq = bench_data.t256_table()
@@ -512,22 +522,33 @@ def test_arithmetic_fast_kernels_full_occupancy_stress(mode, dev):
         base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(256)])
         sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 256, 1).contiguous()
         model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
-    assert model.fast_path(chunk_len)
+    if isinstance(model, models.AecModel):
+        assert model.fast_path(chunk_len)
     ref = model.encode_batch(sym, any_parameter_kernels=True)
     torch.cuda.synchronize()
     stride = ref.stride
     nwords = int((ref.nbits.max().item() + 31) // 32)
-    b = ref.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
+    back = mode in ("rans", "tans", "rans_total_3000")  # ANS streams end at the slot end, the others start at its front
+
+    def words(e):
+        rows = e.data[:n_chunks * stride].view(n_chunks, stride)
+        rows = rows[:, stride - 4 * nwords:] if back else rows[:, :4 * nwords]
+        return rows.contiguous().view(torch.int32)
+
+    b = words(ref)
     full = (ref.nbits.to(torch.int64)[:, None] // 32)
     col = torch.arange(nwords, device=dev)[None, :]
+    whole = (col >= nwords - full) if back else (col < full)
+    ref_nbits = ref.nbits.clone()
     del ref
     for rep in range(3):
         enc = model.encode_batch(sym)
         dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
         torch.cuda.synchronize()
         assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
-        a = enc.data[:n_chunks * stride].view(n_chunks, stride)[:, :4 * nwords].contiguous().view(torch.int32)
-        assert int(((a != b) & (col < full)).sum()) == 0, f"rep {rep}: stream words differ from the any-parameter kernel"
+        assert torch.equal(enc.nbits, ref_nbits)
+        a = words(enc)
+        assert int(((a != b) & whole).sum()) == 0, f"rep {rep}: stream words differ from the any-parameter kernel"
         assert torch.equal(dec[:, :chunk_len], sym), f"rep {rep}: decode"
         del enc, dec, a
 
