@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "scl_tans_internal.h"
+#include "scl_rans_internal.h"
 
 __device__ __forceinline__ u32 tans_find_bin(const u32 *cum, u32 K, u32 slot) {
     u32 lo = 0, hi = K;
@@ -187,9 +188,23 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
                 "tans_model_create: total frequency %llu is not a power of two (assert at tANS.py:42-44)",
                 (unsigned long long)M);
     const u64 L = range_factor * M;
-    SCL_REQUIRE(L <= (1ull << 26), "tans_model_create: RANGE_FACTOR*M = %llu exceeds the 2^26-entry table budget",
-                (unsigned long long)L);
+    // companion rANS model (same stream, no tables): see scl_tans_model::rans
+    scl_rans_model *rans = nullptr;
+    if (L > 8192 && L <= (1ull << 30)) {
+        if (scl_rans_model_create(h_freq, K, range_factor, 1, size_bits, &rans) == SCL_OK && rans && !rans->fast) {
+            scl_rans_model_destroy(rans);
+            rans = nullptr;
+        }
+    }
+    if (L > (1ull << 26) && !rans) {
+        scl_set_error("tans_model_create: RANGE_FACTOR*M = %llu exceeds the 2^26-entry table budget and the model is "
+                      "outside the table-free rANS kernels (M <= 4096, RANGE_FACTOR a power of two <= 2^23)",
+                      (unsigned long long)L);
+        return SCL_E_PARAM;
+    }
     scl_tans_model *m = new scl_tans_model();
+    m->rans = rans;
+    m->tables = (L <= (1ull << 26)) ? 1u : 0u;
     m->dev.K = K;
     m->dev.size_bits = size_bits;
     m->dev.M = (u32)M;
@@ -214,12 +229,12 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     alloc(&m->d_cum, 256);
     alloc(&m->d_nbits, 256);
     alloc(&m->d_thresh, 256);
-    alloc(&m->d_enc, L);
-    alloc(&m->d_dec_sym, L);
-    alloc(&m->d_dec_xs, L);
+    alloc(&m->d_enc, m->tables ? L : 1);
+    alloc(&m->d_dec_sym, m->tables ? L : 1);
+    alloc(&m->d_dec_xs, m->tables ? L : 1);
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, h_freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && m->tables) {
         const u32 n_thr = (u32)(L > K ? L : K);
         hipLaunchKernelGGL(tans_build_tables, dim3((n_thr + 255) / 256), dim3(256), 0, 0, K, (u32)M, (u32)range_factor,
                            m->dev.m_log2, m->dev.nsb, m->d_freq, m->d_cum, m->d_enc, m->d_nbits, m->d_thresh,
@@ -239,8 +254,8 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     m->dev.d_thresh = m->d_thresh;
     m->dev.d_dec_sym = m->d_dec_sym;
     m->dev.d_dec_xs = m->d_dec_xs;
-    m->dev.lds_tables = (2 * L * sizeof(u32) <= TANS_LDS_BUDGET) ? 1u : 0u;
-    const int rc = tans_fast_build_tables(m, h_freq, cum);
+    m->dev.lds_tables = (m->tables && 2 * L * sizeof(u32) <= TANS_LDS_BUDGET) ? 1u : 0u;
+    const int rc = m->tables ? tans_fast_build_tables(m, h_freq, cum) : SCL_OK;
     if (rc != SCL_OK) {
         scl_tans_model_destroy(m);
         return rc;
@@ -257,6 +272,7 @@ extern "C" void scl_tans_model_destroy(scl_tans_model *m) {
     if (m->d_fenc_sym) (void)hipFree(m->d_fenc_sym);
     if (m->d_fenc_tab) (void)hipFree(m->d_fenc_tab);
     if (m->d_fdec_tab) (void)hipFree(m->d_fdec_tab);
+    if (m->rans) scl_rans_model_destroy(m->rans);
     delete m;
 }
 
@@ -270,7 +286,7 @@ extern "C" int scl_tans_model_info(const scl_tans_model *m, scl_rans_info *info)
     info->size_bits = m->dev.size_bits;
     info->num_bits_out = 1;
     info->max_bits_per_symbol = m->max_bits_per_symbol;
-    info->fast_path = m->dev.lds_tables;
+    info->fast_path = (m->fast || m->rans) ? 1u : m->dev.lds_tables;
     return SCL_OK;
 }
 
@@ -283,6 +299,8 @@ extern "C" uint64_t scl_tans_slot_bytes(const scl_tans_model *m, uint64_t n_symb
 extern "C" int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, uint32_t *h_nbits, uint32_t *h_thresh,
                                      uint32_t *h_dec_sym, uint32_t *h_dec_xs) {
     SCL_REQUIRE(m, "tans_model_tables: null model");
+    SCL_REQUIRE(m->tables, "tans_model_tables: RANGE_FACTOR*M = %llu entries are above the 2^26-entry budget; this "
+                           "model runs on the table-free rANS kernels", (unsigned long long)m->dev.L);
     const u64 Lb = (u64)m->dev.L * sizeof(u32), Kb = (u64)m->dev.K * sizeof(u32);
     if (h_enc) SCL_HIP_TRY(hipMemcpy(h_enc, m->d_enc, Lb, hipMemcpyDeviceToHost));
     if (h_nbits) SCL_HIP_TRY(hipMemcpy(h_nbits, m->d_nbits, Kb, hipMemcpyDeviceToHost));
@@ -308,6 +326,15 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
+    if (m->rans && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+        out_stride >= scl_rans_slot_bytes(m->rans, chunk_len)) {  // same stream from the table-free rANS kernels
+        rans_fast_encode_launch(m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
+    SCL_REQUIRE(m->tables, "tans_encode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
+                           "16-byte aligned symbol rows and slots of scl_tans_slot_bytes");
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (768 + (m->dev.lds_tables ? m->dev.L : 0)) * sizeof(u32);
@@ -332,6 +359,14 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
+    if (m->rans && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
+        rans_fast_decode_launch(m->rans, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
+    SCL_REQUIRE(m->tables, "tans_decode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
+                           "16-byte aligned buffers");
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (m->dev.lds_tables ? 2 * m->dev.L : 4) * sizeof(u32);
@@ -345,8 +380,10 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
 // ---- single-chunk host drivers --------------------------------------------------------------------------
 static int tans_run_enc(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
                         u32 *d_nbits, u32 *d_status, void *, u64) {
-    return scl_tans_encode_batch((const scl_tans_model *)model, d_sym, n, nullptr, n, 1, d_out, out_stride, d_bit_off,
-                                 d_nbits, d_status, nullptr);
+    const scl_tans_model *m = (const scl_tans_model *)model;
+    // one row: its stride is free, and a multiple of 16 lets a table-less model reach the kernels that serve it
+    return scl_tans_encode_batch(m, d_sym, m->tables ? n : scl_round_up(n, 16), nullptr, n, 1, d_out, out_stride,
+                                 d_bit_off, d_nbits, d_status, nullptr);
 }
 static u64 tans_slot(const void *model, u64 n) { return scl_tans_slot_bytes((const scl_tans_model *)model, n); }
 static int tans_run_dec(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,

@@ -27,10 +27,18 @@ struct TansFastDev {
     const u32 *d_dec_tab;    // [L]   state - L -> (x_shrunk << 8) | symbol
 };
 
+struct scl_rans_model;
+
 struct scl_tans_model {
     TansDev dev;
     TansFastDev fdev;
     u32 fast;
+    // tANS is rANS with its per-step results cached (tANS.py:88-99, :208-215) and writes the same stream: when the
+    // tables do not fit LDS the tuned rANS kernels serve the model without any table; with RANGE_FACTOR * M above
+    // the 2^26-entry budget (the reference's default RANGE_FACTOR = 2^16 with M = 4096 asks for 2^28 entries) that
+    // is the only route and no lookup tables are built (`tables` = 0)
+    scl_rans_model *rans;
+    u32 tables;
     u32 max_bits_per_symbol;
     u32 *d_freq, *d_cum, *d_enc, *d_nbits, *d_thresh, *d_dec_sym, *d_dec_xs;
     uint4 *d_fenc_sym;
