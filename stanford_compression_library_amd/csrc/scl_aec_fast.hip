@@ -4,7 +4,7 @@
 //   ArithmeticDecoder.decode_step_core / decode_block                               :177-201, :203-287
 //   AdaptiveIIDFreqModel / AdaptiveOrderKFreqModel   scl/compressors/probability_models.py:70-92, :95-160
 //
-// Served models (aec_fast_ok): PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, adaptive IID or order-k model with
+// Served models (aec_fast_ok): PRECISION = 32, adaptive IID or order-k model with
 // alphabet 2..16 and at most 16 contexts (K^k <= 16: order-1 K <= 16, order-2 K <= 4, ...), totals that stay
 // below 2^15 and below the model's rescale threshold for the whole chunk.  Everything else -> scl_aec.hip.
 //
@@ -51,6 +51,7 @@ struct AecFastDev {
     u32 nctx;       // K^k <= 16
     u32 ctx_magic;  // ceil(2^16 / nctx): (v * magic) >> 16 == v / nctx for v < 272
     u32 total0;     // initial total of a row
+    u32 size_bits;  // DATA_BLOCK_SIZE_BITS (1..32)
     u32 initX[8];   // 16 packed u16: EXCLUSIVE cumulative initial counts X[j] = sum_{i<j}, padded with the total
 };
 
@@ -124,8 +125,8 @@ __global__ void __launch_bounds__(AF_THREADS)
     const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
     AfWriter wr;
     wr.init(out + chunk * out_stride);
-    wr.put(n, 32);
-    u32 st = 0;
+    wr.put(P.size_bits < 32 ? (n & ((1u << P.size_bits) - 1u)) : n, P.size_bits);  // header, :92-99
+    u32 st = (P.size_bits < 32 && (n >> P.size_bits)) ? SCL_ST_SIZE : 0u;
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 pending = 0;  // E3 steps not yet resolved (<= 32 * n < 2^20)
     u32 ctx = 0;
@@ -259,8 +260,8 @@ __global__ void __launch_bounds__(AF_THREADS)
     u32 st = 0;
     AfReader rd;
     rd.init(in, in_size_bytes, bit_off[chunk], nbits);
-    u32 n = rd.get(32);
-    if (nbits < 32) {
+    u32 n = rd.get(P.size_bits);
+    if (nbits < P.size_bits) {
         st |= SCL_ST_TRUNCATED;
         n = 0;
     }
@@ -270,7 +271,7 @@ __global__ void __launch_bounds__(AF_THREADS)
         n = 0;
     }
     if (n == 0) {  // quirk Q5, as in scl_aec.hip
-        consumed[chunk] = (st == 0) ? 32 + 2 : 0;
+        consumed[chunk] = (st == 0) ? P.size_bits + 2 : 0;
         if (status) status[chunk] = st;
         return;
     }
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (slo < lo || shi > hi) break;
     }
     if (e == 32) e = 31;
-    consumed[chunk] = (u32)((i64)(used + 32) - ((i64)e - 1));
+    consumed[chunk] = (u32)((i64)(used + P.size_bits) - ((i64)e - 1));
     if (status) status[chunk] = st;
 }
 
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(AF_THREADS)
 bool aec_fast_ok(const scl_aec_model *m, u64 max_symbols) {
     const AecDev &d = m->dev;
     if (d.kind != SCL_MODEL_IID && d.kind != SCL_MODEL_ORDERK) return false;
-    if (d.K < 2 || d.K > 16 || d.ctx_mod > 16 || d.P != 32 || d.size_bits != 32) return false;
+    if (d.K < 2 || d.K > 16 || d.ctx_mod > 16 || d.P != 32) return false;
     const u64 total_max = (u64)d.total0 + max_symbols;  // IID: total; ORDERK: bound on a row total and on any count
     if (total_max >= 32768 || total_max >= d.max_total) return false;
     return true;
@@ -396,6 +397,7 @@ static AecFastDev aec_fast_dev(const scl_aec_model *m) {
         if (j < f.K) acc += m->h_freq[j];
     }
     f.total0 = acc;
+    f.size_bits = m->dev.size_bits;
     for (u32 r = 0; r < 8; ++r) f.initX[r] = X[2 * r] | (X[2 * r + 1] << 16);
     return f;
 }

@@ -5,7 +5,7 @@
 //   AdaptiveIIDFreqModel                     scl/compressors/probability_models.py:70-92
 //
 // Served models (aec_iid_ok): kind IID, alphabet 17..256 (smaller ones are a single row of scl_aec_fast.hip),
-// PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, initial total + chunk length < 2^15 and below the model's rescale
+// PRECISION = 32, initial total + chunk length < 2^15 and below the model's rescale
 // threshold (so the halving rule :86-92 cannot fire inside a chunk).
 //
 // Model layout: two levels of cumulative counts, all u16, 32-byte rows [row][thread] in LDS:
@@ -30,6 +30,7 @@
 
 struct AecIidDev {
     u32 K, total0;
+    u32 size_bits;  // DATA_BLOCK_SIZE_BITS (1..32)
     const u32 *d_init;  // 17 rows x 8 packed u32: XB, then IC[0..15], built from the initial frequencies
 };
 
@@ -87,8 +88,8 @@ __global__ void __launch_bounds__(AI_THREADS)
     const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
     AfWriter wr;
     wr.init(out + chunk * out_stride);
-    wr.put(n, 32);
-    u32 st = 0;
+    wr.put(P.size_bits < 32 ? (n & ((1u << P.size_bits) - 1u)) : n, P.size_bits);  // header, :92-99
+    u32 st = (P.size_bits < 32 && (n >> P.size_bits)) ? SCL_ST_SIZE : 0u;
     u32 low = 0, hm = 0xFFFFFFFFu, pending = 0;
     u32 T = P.total0;  // the total of an i.i.d. model is its initial total plus the symbols seen
     u32 nextw = 0;
@@ -225,8 +226,8 @@ __global__ void __launch_bounds__(AI_THREADS)
     u32 st = 0;
     AfReader rd;
     rd.init(in, in_size_bytes, bit_off[chunk], nbits);
-    u32 n = rd.get(32);
-    if (nbits < 32) {
+    u32 n = rd.get(P.size_bits);
+    if (nbits < P.size_bits) {
         st |= SCL_ST_TRUNCATED;
         n = 0;
     }
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(AI_THREADS)
         n = 0;
     }
     if (n == 0) {  // quirk Q5, as in scl_aec.hip
-        consumed[chunk] = (st == 0) ? 32 + 2 : 0;
+        consumed[chunk] = (st == 0) ? P.size_bits + 2 : 0;
         if (status) status[chunk] = st;
         return;
     }
@@ -339,14 +340,14 @@ __global__ void __launch_bounds__(AI_THREADS)
         if (slo < lo || shi > hi) break;
     }
     if (e == 32) e = 31;
-    consumed[chunk] = (u32)((i64)(used + 32) - ((i64)e - 1));
+    consumed[chunk] = (u32)((i64)(used + P.size_bits) - ((i64)e - 1));
     if (status) status[chunk] = st;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
 bool aec_iid_ok(const scl_aec_model *m, u64 max_symbols) {
     const AecDev &d = m->dev;
-    if (d.kind != SCL_MODEL_IID || d.K < 17 || d.K > 256 || d.P != 32 || d.size_bits != 32 || !m->d_iid_init)
+    if (d.kind != SCL_MODEL_IID || d.K < 17 || d.K > 256 || d.P != 32 || !m->d_iid_init)
         return false;
     const u64 total_max = (u64)d.total0 + max_symbols;
     return total_max < 32768 && total_max < d.max_total;
@@ -374,6 +375,7 @@ static AecIidDev aec_iid_dev(const scl_aec_model *m) {
     AecIidDev f;
     f.K = m->dev.K;
     f.total0 = m->dev.total0;
+    f.size_bits = m->dev.size_bits;
     f.d_init = m->d_iid_init;
     return f;
 }

@@ -4,7 +4,7 @@
 //   ArithmeticDecoder.decode_step_core / decode_block                               :177-201, :203-287
 //   FixedFreqModel                                   scl/compressors/probability_models.py:57-67
 //
-// Served models (aec_static_ok): PRECISION = 32, DATA_BLOCK_SIZE_BITS = 32, alphabet 2..256, total <= 2^16.
+// Served models (aec_static_ok): PRECISION = 32, alphabet 2..256, total <= 2^16.
 // The model is read-only, so nothing is private to a lane but its interval: the {c, c + f} table (and, for totals
 // up to 4096, a slot -> symbol table for the decoder) sits in LDS once per workgroup, and the kernels run at the
 // occupancy of the rANS fast kernels with their line-granular I/O (scl_ans_fast_io.h): symbols arrive as whole
@@ -23,6 +23,7 @@
 
 struct AecStaticDev {
     u32 K, T;
+    u32 size_bits;  // DATA_BLOCK_SIZE_BITS (1..32)
     const u32 *d_freq, *d_cum;
 };
 
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     const double xT = af_recip((double)P.T);
     AsOut wr;
     wr.init(tid, out + chunk * out_stride);
-    wr.put(lds, n, 32);
+    wr.put(lds, P.size_bits < 32 ? (n & ((1u << P.size_bits) - 1u)) : n, P.size_bits);  // header, :92-99
     u32 low = 0, hm = 0xFFFFFFFFu, pending = 0, bad = 0;
 
     auto code_word = [&](u32 w, u32 cnt) {  // up to four symbols, first symbol in the low byte
@@ -155,7 +156,8 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     const u64 total = wr.finish(lds);
     out_bit_off[chunk] = chunk * out_stride * 8;
     out_nbits[chunk] = (u32)total;
-    if (status) status[chunk] = (bad >= P.K) ? SCL_ST_SYMBOL : 0u;
+    if (status)
+        status[chunk] = ((bad >= P.K) ? SCL_ST_SYMBOL : 0u) | ((P.size_bits < 32 && (n >> P.size_bits)) ? SCL_ST_SIZE : 0u);
 }
 
 // LUT = true: total <= 4096, the decoder's search is one byte read by target slot; else a binary search on c
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     if (chunk >= n_chunks) return;
     const u32 nbits = in_nbits[chunk];
     u32 st = 0;
-    if (nbits < 32) {
+    if (nbits < P.size_bits) {
         out_lens[chunk] = 0;
         consumed[chunk] = 0;
         if (status) status[chunk] = SCL_ST_TRUNCATED;
@@ -180,14 +182,14 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     }
     AsIn rd;
     rd.init(in, in_size_bytes, bit_off[chunk], lds, tid, nbits);
-    u32 n = rd.get(lds, 32);
+    u32 n = rd.get(lds, P.size_bits);
     out_lens[chunk] = n;
     if (n > out_cap) {
         st |= SCL_ST_CAPACITY;
         n = 0;
     }
     if (n == 0) {  // quirk Q5, as in scl_aec.hip
-        consumed[chunk] = (st == 0) ? 32 + 2 : 0;
+        consumed[chunk] = (st == 0) ? P.size_bits + 2 : 0;
         if (status) status[chunk] = st;
         return;
     }
@@ -302,14 +304,14 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
         if (slo < lo || shi > hi) break;
     }
     if (e == 32) e = 31;
-    consumed[chunk] = (u32)((i64)((u64)used + 32) - ((i64)e - 1));
+    consumed[chunk] = (u32)((i64)((u64)used + P.size_bits) - ((i64)e - 1));
     if (status) status[chunk] = st;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
 bool aec_static_ok(const scl_aec_model *m) {
     const AecDev &d = m->dev;
-    return d.kind == SCL_MODEL_FIXED && d.K >= 2 && d.K <= 256 && d.P == 32 && d.size_bits == 32 &&
+    return d.kind == SCL_MODEL_FIXED && d.K >= 2 && d.K <= 256 && d.P == 32 &&
            d.total0 <= 65536 && (u64)d.total0 < d.max_total;
 }
 
@@ -317,6 +319,7 @@ static AecStaticDev aec_static_dev(const scl_aec_model *m) {
     AecStaticDev f;
     f.K = m->dev.K;
     f.T = m->dev.total0;
+    f.size_bits = m->dev.size_bits;
     f.d_freq = m->dev.d_freq;
     f.d_cum = m->dev.d_cum;
     return f;

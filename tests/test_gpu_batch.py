@@ -588,28 +588,29 @@ def test_random_arithmetic_models_vs_oracle(seed, dev):
     cap = 400
     lens = np.concatenate([[0, 1, 2, 127, 128, 129, 400], rng.integers(0, cap + 1, 17)]).astype(np.int32)
     kind = ["fixed", "iid", "orderk"][seed % 3]
+    sb = int(rng.choice([32, 32, 9, 17, 24, 31]))  # DATA_BLOCK_SIZE_BITS (cap = 400 < 2^9)
     if kind == "fixed":
         K = int(rng.integers(2, 257))
         T = int(rng.integers(K, 65537))
         f = np.maximum(1, np.floor(rng.dirichlet(np.full(K, float(rng.choice([0.1, 1.0, 10.0])))) * (T - K)).astype(np.int64) + 1)
         f[np.argmax(f)] += T - f.sum()
         f = f.astype(np.uint32)
-        model = models.AecModel(0, f.tolist(), K, 0, 1 << 30, 32, 32)
-        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_FIXED, K, f_init=f)
-        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_FIXED, K, f_init=f)
+        model = models.AecModel(0, f.tolist(), K, 0, 1 << 30, 32, sb)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_FIXED, K, f_init=f, size_bits=sb)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_FIXED, K, f_init=f, size_bits=sb)
         p = f / f.sum()
     elif kind == "iid":
         K = int(rng.integers(2, 257))
         f = rng.integers(1, 60, K).astype(np.uint32)
-        model = models.AecModel(1, f.tolist(), K, 0, 1 << 30, 32, 32)
-        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_IID, K, f_init=f)
-        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_IID, K, f_init=f)
+        model = models.AecModel(1, f.tolist(), K, 0, 1 << 30, 32, sb)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_IID, K, f_init=f, size_bits=sb)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_IID, K, f_init=f, size_bits=sb)
         p = rng.dirichlet(np.full(K, 0.3))
     else:
         K, k = [(2, 1), (2, 3), (3, 2), (4, 2), (7, 1), (16, 1), (13, 1), (16, 0), (4, 1)][int(rng.integers(0, 9))]
-        model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
-        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=k)
-        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_ORDERK, K, k=k)
+        model = models.AecModel(2, None, K, k, 1 << 30, 32, sb)
+        o_enc = lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=k, size_bits=sb)
+        o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_ORDERK, K, k=k, size_bits=sb)
         p = rng.dirichlet(np.full(K, 0.5))
     assert model.fast_path(cap), kind
     sym = rng.choice(K, (lens.size, cap), p=p).astype(np.uint8)
