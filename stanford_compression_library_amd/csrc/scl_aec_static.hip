@@ -121,11 +121,10 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
 
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-    Line128 cur, nxt;
-    if (n_lines) cur.load(src16);
+    Line128 cur;  // no second buffer: with it the kernel needs more than its 128 registers (4 waves per SIMD hide the load)
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
-        nxt.load(src16 + 8 * min(t + 1, n_lines - 1));  // next line; unconditional (see scl_rans_fast.hip)
+        cur.load(src16 + 8 * t);
 #pragma unroll 1
         for (u32 q = 0; q < 8; ++q) {
             const uint4 v = cur.v[0];
@@ -136,7 +135,6 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             code_word(v.z, 4);
             code_word(v.w, 4);
         }
-        cur = nxt;
     }
     u32 i = n_lines << 7;
     for (; i + 4 <= n; i += 4) code_word(*reinterpret_cast<const u32 *>(src + i), 4);  // ragged tail

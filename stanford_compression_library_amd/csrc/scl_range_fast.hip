@@ -240,11 +240,10 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
 
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-    RgLine128 cur, nxt;
-    if (n_lines) cur.load(src16);
+    RgLine128 cur;  // no second buffer: with one the kernel spilled 100 bytes per lane (4 waves per SIMD hide the load)
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
-        if (t + 1 < n_lines) nxt.load(src16 + 8 * (t + 1));
+        cur.load(src16 + 8 * t);
 #pragma nounroll
         for (int q = 0; q < 4; ++q) {
             rg_encode16<GEN>(cur.v[0], low, range, o, bad, lds, tab, md);
@@ -252,7 +251,6 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
 #pragma unroll
             for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
         }
-        cur = nxt;
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16)
@@ -437,6 +435,9 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     return s;
 }
 
+// (the 144 bytes of private segment this kernel reports are the `a[8]` line accumulator below, which the compiler keeps
+// as an indexed stack array because it declines to unroll the 16-symbol body eight times -- eight 16-byte scratch
+// stores and loads per 128 symbols, not register spills)
 template <bool GEN, bool LUT>
 __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,

@@ -151,7 +151,10 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     for (u32 t = 0; t < n_lines; ++t) {
         // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
         // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
-        nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+        if (!CHECK_SYM)
+            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+        else if (t + 1 < n_lines)  // the checking variants have no register to spare: this form does not spill
+            nxt.load(src16 + 8 * (t + 1));
         if (!CHECK_SYM) {
             // straight-line code for the whole line: an inner loop holding only stores would make the compiler
             // drain vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once

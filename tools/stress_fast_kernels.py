@@ -9,20 +9,33 @@ from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 n_chunks, chunk_len = int(os.environ.get("NCHUNKS", 262144)), 4096
 mode = os.environ.get("MODEL", "fixed")
-if mode in ("fixed", "rans", "tans", "range", "iid"):
+if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "rans_m3000", "fixed_k64"):
     freq = bench_data.t256_table()
+    if mode in ("rans_k64", "rans_k200", "fixed_k64"):  # alphabets below 256: the symbol-checking encoder variants
+        K = 64 if mode.endswith("k64") else 200
+        freq = freq[:K].copy()
+        freq[0] += 4096 - freq.sum()
+    if mode == "rans_m3000":  # a total that is not a power of two
+        freq = np.maximum(1, (freq.astype(np.int64) * 3000) // 4096)
+        freq[np.argmax(freq)] += 3000 - freq.sum()
     sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
-    model = {"fixed": lambda: models.AecModel(0, freq.tolist(), 256, 0, 1 << 30, 32, 32),
+    model = {"fixed": lambda: models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
              "iid": lambda: models.AecModel(1, [1] * 256, 256, 0, 1 << 30, 32, 32),
              "rans": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "rans_k64": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "rans_k200": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "rans_m3000": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "fixed_k64": lambda: models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
              "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
              "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
 else:
     base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(512)])
     sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 512, 1).contiguous()
     model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
-if hasattr(model, 'fast_path'):
+if isinstance(model, models.AecModel):
     assert model.fast_path(chunk_len)
+elif hasattr(model, 'fast_path'):
+    assert model.fast_path()
 # reference streams from the any-parameter kernels
 ref = model.encode_batch(sym, any_parameter_kernels=True)
 torch.cuda.synchronize()
@@ -34,7 +47,7 @@ for rep in range(int(os.environ.get("REPS", 10))):
     dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
     torch.cuda.synchronize()
     assert torch.equal(enc.nbits, ref.nbits)
-    if mode in ("rans", "tans"):  # streams end at the slot end: compare the last whole words
+    if mode.startswith("rans") or mode == "tans":  # streams end at the slot end: compare the last whole words
         a = enc.data[:n_chunks * stride].view(n_chunks, stride)[:, stride - 4 * nwords:].contiguous().view(torch.int32)
         b = ref.data[:n_chunks * stride].view(n_chunks, stride)[:, stride - 4 * nwords:].contiguous().view(torch.int32)
         col = torch.arange(a.shape[1], device=dev)[None, :]
