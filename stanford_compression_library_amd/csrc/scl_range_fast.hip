@@ -8,8 +8,8 @@
 //           (a symbol releases 0..4 bytes), appended to a 64-bit byte accumulator, completed words parked in a
 //           per-lane LDS ring ([word][thread], conflict-free) and stored 64 bytes at a time, front to back.
 //   decode: stream read through the LDS word ring of scl_rans_fast.hip's decoder; the symbol search
-//           max{s : low + c[s]*r <= state} (:232-237) is evaluated as q = (state - low) / r (float estimate +
-//           exact integer correction), then one slot -> symbol LUT read; 64 symbols per 64-byte store burst.
+//           max{s : low + c[s]*r <= state} (:232-237) is evaluated as q = (state - low) / r (exact, in binary64
+//           with a Newton-refined v_rcp_f32), then ONE read of a slot -> {c, f, s} table; 128 symbols per store burst.
 #include <vector>
 
 #include "scl_range_internal.h"
@@ -365,17 +365,17 @@ struct RgIn {  // forward bit reader over a per-lane LDS word ring (same scheme 
     }
 };
 
-// floor(d / r) for r >= 1: float estimate (exact to +-1 because the quotient is < 2^13 for valid streams)
-// followed by an exact integer correction; quotients that do not fit are clamped by the caller.
+// floor(d / r) for any d < 2^32 and r >= 1, exactly: trunc((d + 0.5) * x) in binary64 with x = 1 / r good to 2^-42
+// (v_rcp_f32 of the rounded divisor, 2^-21, squared by one Newton step on the exact divisor).  (d + 0.5) / r is at
+// least 0.5 / r away from an integer, the error of the product is below (d + 0.5) / r * 2^-41 -- less than that for
+// every d < 2^32.  Ten full-rate instructions; the float-with-directed-rounding version this replaces compiled to
+// 35 (the rounding-mode conversions and the IEEE reciprocal are emulated on gfx950).
 __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
-    u32 q = (u32)(__uint2float_rz(d) * __frcp_rn(__uint2float_ru(r)));  // never above the true quotient by more than 1
-    u32 t = q * r;
-    if (t > d) {
-        --q;
-        t -= r;
-    }
-    if (d - t >= r) ++q;
-    return q;
+    const double rd = (double)r;
+    const double x0 = (double)__builtin_amdgcn_rcpf((float)r);
+    const double e = __builtin_fma(-rd, x0, 1.0);
+    const double x = __builtin_fma(x0, e, x0);
+    return (u32)(((double)d + 0.5) * x);
 }
 
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
@@ -383,13 +383,16 @@ __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
 // binary search on the cumulative counts (K = alphabet size rides in md.k)
 template <bool GEN, bool LUT>
 __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
-                                                const u8 *s2s, const RgDivM &md, u32 slot_max) {
+                                                const RgDivM &md, u32 slot_max) {
     const u32 rr = rg_range_over_m<GEN>(range, md);
     u32 q = rg_div(state - low, rr);
     q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
     u32 s;
-    if (LUT) {
-        s = s2s[q];
+    uint2 e;
+    if (LUT) {  // one read: slot -> {c | s << 24, f}
+        e = *reinterpret_cast<const uint2 *>(tab + q * 8);
+        s = e.x >> 24;
+        e.x &= 0xFFFFFFu;
     } else {
         s = 0;
 #pragma unroll
@@ -398,8 +401,8 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
             const u32 ct = *reinterpret_cast<const u32 *>(tab + min(t, 255u) * 8);
             s = (t < md.k && ct <= q) ? t : s;
         }
+        e = *reinterpret_cast<const uint2 *>(tab + s * 8);
     }
-    const uint2 e = *reinterpret_cast<const uint2 *>(tab + s * 8);
     low += e.x * rr;
     range = rr * e.y;
     const u32 lk = r.look();
@@ -409,7 +412,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     const u32 sh = 8 * nb1;
     const u32 range_s = range << sh;
     if (__builtin_expect(range_s >= RG_BOTTOM, 1)) {
-        state = (state << sh) | ((lk >> 1) >> (31 - sh));  // the next nb1 bytes (sh may be 0)
+        state = (u32)(((((u64)state) << 32) | lk) << sh >> 32);  // the next nb1 bytes (sh may be 0): one 64-bit shift
         low <<= sh;
         range = range_s;
         r.advance(lds, sh);
@@ -447,14 +450,21 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                                                                        u32 out_cap, u32 *__restrict__ out_lens,
                                                                        u32 *__restrict__ consumed,
                                                                        u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char s_lds[RGD_RING_BYTES + 256 * 8 + 4096];
+    // [0, 128 KiB) word ring, then the table the symbol search reads: slot -> {c | s << 24, f} for totals up to 4096
+    // (32 KiB, one read per symbol), else the 256 {c, f} pairs the binary search walks
+    __shared__ __attribute__((aligned(16))) char s_lds[RGD_RING_BYTES + (LUT ? 4096 * 8 : 256 * 8)];
     char *lds = s_lds;
     const char *tab = s_lds + RGD_RING_BYTES;
-    const u8 *s2s = reinterpret_cast<const u8 *>(s_lds + RGD_RING_BYTES + 256 * 8);
     const u32 M = P.M;
-    if (threadIdx.x < 256) reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[threadIdx.x] = P.d_enc_tab[threadIdx.x];
-    if (LUT)
-        for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) s_lds[RGD_RING_BYTES + 256 * 8 + i] = (char)P.d_slot2sym[i];
+    if (LUT) {
+        for (u32 i = threadIdx.x; i < M; i += RGD_THREADS) {
+            const u32 sy = P.d_slot2sym[i];
+            const uint2 cf = P.d_enc_tab[sy];
+            reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[i] = make_uint2(cf.x | (sy << 24), cf.y);
+        }
+    } else if (threadIdx.x < 256) {
+        reinterpret_cast<uint2 *>(s_lds + RGD_RING_BYTES)[threadIdx.x] = P.d_enc_tab[threadIdx.x];
+    }
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RGD_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -496,7 +506,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                 u32 o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32 s = rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, s2s, md, slot_max);
+                    const u32 s = rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, md, slot_max);
                     o |= s << (8 * j);
                 }
                 r.maybe_refill(lds);
@@ -510,7 +520,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     for (; i < n; ++i) {  // ragged tail
-        dst[i] = (u8)rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, s2s, md, slot_max);
+        dst[i] = (u8)rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, md, slot_max);
         if ((i & 3u) == 3u) r.maybe_refill(lds);
     }
     const u32 used_bits = r.consumed();

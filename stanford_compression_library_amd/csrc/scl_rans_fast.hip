@@ -232,7 +232,7 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
         const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ML_T) - 1u) << 3)));
         const u32 xn = __umul24(x >> (ML_T + 3), e.x) + e.y;
         const u32 cl = (u32)__builtin_clz(xn);
-        x = __builtin_amdgcn_alignbit(xn, lk, 32 - cl);  // top-aligned again (its low 3 bits are look-ahead, ignored)
+        x = (u32)(((((u64)xn) << 32) | lk) << cl >> 32);  // v_lshlrev_b64: top-aligned again (low 3 bits = look-ahead)
         used = cl - 3;
         return e.x;
     }
