@@ -151,6 +151,60 @@ struct AnsBackWriter {
     }
 };
 
+// Wave-cooperative store of one decoded 128-byte line per lane.
+// A lane that stores its own line issues eight 16-byte stores; the 64 lanes of a store instruction hit 64 different
+// lines, and every 16-byte piece travels to L2 as its own write request (6.7e7
+// of them per GiB, profiles/r01_final_pmc_summary.txt: TCP_TCC_WRITE_REQ).  When all 64 lanes of the wave are at the
+// same position of equally long chunks (the batch case) the four registers of each half-line are transposed across
+// the lanes l, l+16, l+32, l+48 (v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even
+// rows of its second, v_permlane32_swap does the same for the 32-lane halves: the two butterfly stages of a 4x4
+// transpose, one instruction per pair of dwords, 32 per line), after which those four lanes hold the four pieces of
+// ONE 64-byte half-line and every store instruction writes 16 whole half-lines.  rANS decode of 1 GiB: 0.75 -> 0.62
+// ms (profiles/r01_coop_store_note.txt; the same addresses without the transpose: 0.60, eight adjacent lanes per
+// full line: 0.57).  Ragged batches and partial waves keep the per-lane bursts.
+__device__ __forceinline__ void scl_swap16(u32 &p, u32 &q) {
+    const auto t = __builtin_amdgcn_permlane16_swap(p, q, false, false);
+    p = t[0];
+    q = t[1];
+}
+__device__ __forceinline__ void scl_swap32(u32 &p, u32 &q) {
+    const auto t = __builtin_amdgcn_permlane32_swap(p, q, false, false);
+    p = t[0];
+    q = t[1];
+}
+// afterwards register j of lane (l, k) holds what register k of lane (l, j) held; all 64 lanes must be active
+__device__ __forceinline__ void scl_transpose4(uint4 *a) {
+    scl_swap16(a[0].x, a[1].x); scl_swap16(a[0].y, a[1].y); scl_swap16(a[0].z, a[1].z); scl_swap16(a[0].w, a[1].w);
+    scl_swap16(a[2].x, a[3].x); scl_swap16(a[2].y, a[3].y); scl_swap16(a[2].z, a[3].z); scl_swap16(a[2].w, a[3].w);
+    scl_swap32(a[0].x, a[2].x); scl_swap32(a[0].y, a[2].y); scl_swap32(a[0].z, a[2].z); scl_swap32(a[0].w, a[2].w);
+    scl_swap32(a[1].x, a[3].x); scl_swap32(a[1].y, a[3].y); scl_swap32(a[1].z, a[3].z); scl_swap32(a[1].w, a[3].w);
+}
+struct CoopLineStore {
+    u8 *base;  // lane (l0, k) = (lane & 15, lane >> 4) writes piece k (+4: upper half-line) of the lines of lanes l0 + 16 j
+    u64 stride;
+    bool on;
+    // `key`: any per-lane value that decides how many lines the lane will store and when (the caller's loop counter):
+    // the wave cooperates iff all 64 lanes are present with the same non-zero key.  Rows are out_stride apart.
+    __device__ __forceinline__ void init(u8 *out_sym, u64 c, u64 out_stride, u32 key) {
+        const u32 lane = threadIdx.x & 63u;
+        on = __builtin_amdgcn_ballot_w64(key != 0 && key == (u32)__builtin_amdgcn_readfirstlane((int)key)) == ~0ull;
+        base = out_sym + (c - lane + (lane & 15u)) * out_stride + 16u * (lane >> 4);
+        stride = out_stride;
+    }
+    // a[b] = bytes [16 b, 16 b + 16) of this lane's line, which starts at byte `pos` of its row
+    __device__ __forceinline__ void store(uint4 *a, u32 pos) const {
+        scl_transpose4(a);
+        scl_transpose4(a + 4);
+        // both half-lines of a line back to back (written apart they cost like two partial-line writes)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u8 *q = base + (u64)(16 * j) * stride + pos;
+            *reinterpret_cast<uint4 *>(q) = a[j];
+            *reinterpret_cast<uint4 *>(q + 64) = a[4 + j];
+        }
+    }
+};
+
 struct Line128 {
     uint4 v[8];
     __device__ __forceinline__ void load(const uint4 *p) {

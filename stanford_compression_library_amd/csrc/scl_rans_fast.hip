@@ -352,19 +352,23 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
-    // ... then one full 128-byte line per iteration: eight registers, one burst of eight 16-byte stores
+    // ... then one full 128-byte line per iteration, eight registers: stored cooperatively by the wave when every
+    // lane is here with the same position (CoopLineStore, scl_ans_fast_io.h), else as a burst of eight 16-byte stores
+    CoopLineStore cs;
+    cs.init(out_sym, c, out_stride, i);
 #pragma nounroll
     while (i) {
         uint4 a[8];
 #pragma unroll
         for (int b = 7; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 128;
-        uint4 *p = reinterpret_cast<uint4 *>(dst + i);
-#if RF_ABLATE == 11
-        if (i == 0)  // ablation: only the last burst is stored
-#endif
+        if (cs.on) {
+            cs.store(a, i);
+        } else {
+            uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) p[b] = a[b];
+            for (int b = 0; b < 8; ++b) p[b] = a[b];
+        }
     }
     const u32 used_bits = r.consumed();
     if (used_bits > avail) st |= SCL_ST_TRUNCATED;

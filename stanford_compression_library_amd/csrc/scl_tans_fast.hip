@@ -205,15 +205,21 @@ __global__ void __launch_bounds__(TF_THREADS) tans_decode_fast_kernel(TansFastDe
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
+    CoopLineStore cs;  // whole waves of equally long chunks store cooperatively (scl_ans_fast_io.h)
+    cs.init(out_sym, c, out_stride, i);
 #pragma nounroll
     while (i) {  // one full 128-byte line per iteration
         uint4 a[8];
 #pragma unroll
         for (int b = 7; b >= 0; --b) a[b] = tf_decode16(x, r, lds, tab, idx_mask, cb);
         i -= 128;
-        uint4 *p = reinterpret_cast<uint4 *>(dst + i);
+        if (cs.on) {
+            cs.store(a, i);
+        } else {
+            uint4 *p = reinterpret_cast<uint4 *>(dst + i);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) p[b] = a[b];
+            for (int b = 0; b < 8; ++b) p[b] = a[b];
+        }
     }
     const u32 used_bits = r.consumed();
     if (used_bits > avail) st |= SCL_ST_TRUNCATED;

@@ -737,3 +737,41 @@ def test_tans_reference_default_range_factor(dev):
     assert len(bits) == rn and np.array_equal(bits.packed(), rb)
     out, consumed = tANSDecoder(params).decode_block(bits)
     assert out.data_list == block.data_list and consumed == rn
+
+
+@pytest.mark.parametrize("name", ["rans_default", "tans_rf1"])
+@pytest.mark.parametrize("n", [128, 1000, 4096])
+def test_cooperative_line_store_full_and_partial_waves(name, n, dev):
+    """The rANS / tANS decoders store whole waves of equally long chunks cooperatively (CoopLineStore: the lanes
+    l, l+16, l+32, l+48 share a half-line after a register transpose) and everything else lane by lane.  One launch
+    holds both kinds of wave: 128 equal chunks (two cooperating waves), a wave where one chunk is shorter by a line,
+    a wave with a truncated stream descriptor, and a partial wave; every row must equal its input, bytes of a row
+    beyond the chunk must stay untouched, and a sample is compared with the oracle's decode."""
+    make_model, o_enc, o_dec = CODERS[name]
+    freq = bench_data.t256_table()
+    model = make_model(freq)
+    n_chunks = 64 * 4 + 19
+    sym = bench_data.iid_chunks_host(freq, n_chunks, n, seed=77 + n)
+    lens = np.full(n_chunks, n, dtype=np.int32)
+    lens[128 + 5] = n - 128 if n > 128 else 1  # third wave: one lane a line behind the others
+    d_sym, d_lens = torch.from_numpy(sym).to(dev), torch.from_numpy(lens).to(dev)
+    enc = model.encode_batch(d_sym, lens=d_lens)
+    avail = enc.nbits.clone()
+    avail[192 + 7] = 10  # fourth wave: one stream too short for its header -> that lane leaves early
+    out = model.alloc_decoded(n_chunks, n + 64, dev)
+    out[0].fill_(0xA5)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, avail, n + 64, out=out)
+    torch.cuda.synchronize()
+    status, dec = status.cpu().numpy(), dec.cpu().numpy()
+    assert status[192 + 7] != 0 and int(np.abs(np.delete(status, 192 + 7)).sum()) == 0
+    for c in range(n_chunks):
+        if c == 192 + 7:
+            continue
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        assert (dec[c, lens[c]:] == 0xA5).all(), f"chunk {c}: bytes beyond the chunk were written"
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in (0, 17, 63, 64, 127, 133, 191, 256, n_chunks - 1):
+        bits = _stream_bits(data, offs[c], nbits[c])
+        o_sym, o_used = o_dec(np.packbits(bits), int(nbits[c]), freq)
+        assert o_used == nbits[c] == used[c].item()
+        assert np.array_equal(np.asarray(o_sym), dec[c, :lens[c]])
