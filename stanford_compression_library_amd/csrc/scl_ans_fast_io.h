@@ -153,15 +153,20 @@ struct AnsBackWriter {
 
 // Wave-cooperative store of one decoded 128-byte line per lane.
 // A lane that stores its own line issues eight 16-byte stores; the 64 lanes of a store instruction hit 64 different
-// lines, and every 16-byte piece travels to L2 as its own write request (6.7e7
-// of them per GiB, profiles/r01_final_pmc_summary.txt: TCP_TCC_WRITE_REQ).  When all 64 lanes of the wave are at the
-// same position of equally long chunks (the batch case) the four registers of each half-line are transposed across
-// the lanes l, l+16, l+32, l+48 (v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even
-// rows of its second, v_permlane32_swap does the same for the 32-lane halves: the two butterfly stages of a 4x4
-// transpose, one instruction per pair of dwords, 32 per line), after which those four lanes hold the four pieces of
-// ONE 64-byte half-line and every store instruction writes 16 whole half-lines.  rANS decode of 1 GiB: 0.75 -> 0.62
-// ms (profiles/r01_coop_store_note.txt; the same addresses without the transpose: 0.60, eight adjacent lanes per
-// full line: 0.57).  Ragged batches and partial waves keep the per-lane bursts.
+// lines, and every 16-byte piece travels to L2 as its own write request (6.7e7 of them per GiB: TCP_TCC_WRITE_REQ in
+// profiles/r01_v6_pmc_summary.txt).  When all 64 lanes of the wave are at the same position of equally long chunks
+// (the batch case) the eight registers of a line are transposed across the lanes l, l+8, ..., l+56 -- three butterfly
+// stages: lanes l ^ 8 by DPP (row_ror:8 under a bank mask), l ^ 16 and l ^ 32 by v_permlane16_swap /
+// v_permlane32_swap, which exchange the odd 16-lane rows (32-lane halves) of their first operand with the even ones
+// of their second: one instruction per pair of dwords -- after which those eight lanes hold the eight 16-byte pieces
+// of ONE line and every store instruction writes eight whole lines.  rANS decode of 1 GiB: 0.75 -> 0.60 ms, 1.68e7
+// write requests (profiles/r01_coop_store_note.txt).  Ragged batches and partial waves keep the per-lane bursts.
+__device__ __forceinline__ void scl_swap8(u32 &p, u32 &q) {
+    // banks 0-1 = lanes 0..7 of each 16-lane row, banks 2-3 = lanes 8..15; row_ror:8 reads lane ^ 8
+    const u32 q2 = (u32)__builtin_amdgcn_update_dpp((int)q, (int)p, 0x128, 0xF, 0x3, false);  // lanes 0..7: q = p of lane ^ 8
+    p = (u32)__builtin_amdgcn_update_dpp((int)p, (int)q, 0x128, 0xF, 0xC, false);            // lanes 8..15: p = q of lane ^ 8
+    q = q2;
+}
 __device__ __forceinline__ void scl_swap16(u32 &p, u32 &q) {
     const auto t = __builtin_amdgcn_permlane16_swap(p, q, false, false);
     p = t[0];
@@ -172,15 +177,34 @@ __device__ __forceinline__ void scl_swap32(u32 &p, u32 &q) {
     p = t[0];
     q = t[1];
 }
-// afterwards register j of lane (l, k) holds what register k of lane (l, j) held; all 64 lanes must be active
-__device__ __forceinline__ void scl_transpose4(uint4 *a) {
-    scl_swap16(a[0].x, a[1].x); scl_swap16(a[0].y, a[1].y); scl_swap16(a[0].z, a[1].z); scl_swap16(a[0].w, a[1].w);
-    scl_swap16(a[2].x, a[3].x); scl_swap16(a[2].y, a[3].y); scl_swap16(a[2].z, a[3].z); scl_swap16(a[2].w, a[3].w);
-    scl_swap32(a[0].x, a[2].x); scl_swap32(a[0].y, a[2].y); scl_swap32(a[0].z, a[2].z); scl_swap32(a[0].w, a[2].w);
-    scl_swap32(a[1].x, a[3].x); scl_swap32(a[1].y, a[3].y); scl_swap32(a[1].z, a[3].z); scl_swap32(a[1].w, a[3].w);
+// 8x8 transpose of 16-byte elements across the lanes l, l+8, ..., l+56 (all 64 lanes active): register j of lane
+// (l, k) gets what register k of lane (l, j) held
+__device__ __forceinline__ void scl_transpose8(uint4 *a) {
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        scl_swap8(a[r].x, a[r + 1].x);
+        scl_swap8(a[r].y, a[r + 1].y);
+        scl_swap8(a[r].z, a[r + 1].z);
+        scl_swap8(a[r].w, a[r + 1].w);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r & 2) continue;
+        scl_swap16(a[r].x, a[r + 2].x);
+        scl_swap16(a[r].y, a[r + 2].y);
+        scl_swap16(a[r].z, a[r + 2].z);
+        scl_swap16(a[r].w, a[r + 2].w);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        scl_swap32(a[r].x, a[r + 4].x);
+        scl_swap32(a[r].y, a[r + 4].y);
+        scl_swap32(a[r].z, a[r + 4].z);
+        scl_swap32(a[r].w, a[r + 4].w);
+    }
 }
 struct CoopLineStore {
-    u8 *base;  // lane (l0, k) = (lane & 15, lane >> 4) writes piece k (+4: upper half-line) of the lines of lanes l0 + 16 j
+    u8 *base;  // lane (l0, k) = (lane & 7, lane >> 3) writes piece k of the lines of the lanes l0 + 8 j
     u64 stride;
     bool on;
     // `key`: any per-lane value that decides how many lines the lane will store and when (the caller's loop counter):
@@ -188,20 +212,14 @@ struct CoopLineStore {
     __device__ __forceinline__ void init(u8 *out_sym, u64 c, u64 out_stride, u32 key) {
         const u32 lane = threadIdx.x & 63u;
         on = __builtin_amdgcn_ballot_w64(key != 0 && key == (u32)__builtin_amdgcn_readfirstlane((int)key)) == ~0ull;
-        base = out_sym + (c - lane + (lane & 15u)) * out_stride + 16u * (lane >> 4);
+        base = out_sym + (c - lane + (lane & 7u)) * out_stride + 16u * (lane >> 3);
         stride = out_stride;
     }
     // a[b] = bytes [16 b, 16 b + 16) of this lane's line, which starts at byte `pos` of its row
     __device__ __forceinline__ void store(uint4 *a, u32 pos) const {
-        scl_transpose4(a);
-        scl_transpose4(a + 4);
-        // both half-lines of a line back to back (written apart they cost like two partial-line writes)
+        scl_transpose8(a);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u8 *q = base + (u64)(16 * j) * stride + pos;
-            *reinterpret_cast<uint4 *>(q) = a[j];
-            *reinterpret_cast<uint4 *>(q + 64) = a[4 + j];
-        }
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4 *>(base + (u64)(8 * j) * stride + pos) = a[j];
     }
 };
 
