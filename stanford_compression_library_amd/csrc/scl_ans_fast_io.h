@@ -30,8 +30,11 @@ struct AnsBackWriter {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
     u32 lo;    // pending bits (right-aligned; newest bits are the high ones), < 32 of them
     u32 nacc;  // number of pending bits
-    u32 ra;    // LDS byte address of the ring word that completes next (thread column, wraps inside the ring)
-    u32 fa;    // LDS byte address of the oldest unflushed word
+    // The stream grows towards lower addresses, so the ring is filled from its top row down: ascending rows are then
+    // ascending memory addresses and a flush reads its 16-byte pieces in register order (filled upwards, every
+    // ds_read2 pair arrived swapped and cost two copies).
+    u32 ra;    // LDS byte address of the ring word that completes next (thread column, moves DOWN a row per word, wraps)
+    u32 fa;    // LDS byte address of the lowest row of the oldest unflushed group of 16 words
     u32 pend;  // completed words not yet stored to memory
     u32 nfl;   // words already stored to memory
     u8 *slot_end;
@@ -39,8 +42,8 @@ struct AnsBackWriter {
     __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
         lo = 0;
         nacc = 0;
-        ra = tid * 4;
-        fa = tid * 4;
+        ra = tid * 4 + 31 * THREADS * 4;
+        fa = tid * 4 + 16 * THREADS * 4;
         pend = 0;
         nfl = 0;
         slot_end = slot_end_;
@@ -59,7 +62,7 @@ struct AnsBackWriter {
         // again later); whether the slot advances is arithmetic on the carry out of the 5-bit bit counter
         *ring_at(lds, ra) = __builtin_bswap32(lo2);
         const u32 m = 0u - (nacc2 >> 5);                 // all ones iff the word completed (nacc2 < 64)
-        ra = (ra + (m & (THREADS * 4))) & (RING_BYTES - 1);
+        ra = (ra - (m & (THREADS * 4))) & (RING_BYTES - 1);
         pend -= m;
         const u32 hi = v >> ((32 - nacc) & 31);          // only used when m != 0, which implies nacc >= 1
         lo = (hi & m) | (lo2 & ~m);
@@ -67,7 +70,7 @@ struct AnsBackWriter {
 #else
         if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
             *ring_at(lds, ra) = __builtin_bswap32(lo2);
-            ra = (ra + THREADS * 4) & (RING_BYTES - 1);
+            ra = (ra - THREADS * 4) & (RING_BYTES - 1);
             ++pend;
             lo = v >> (32 - nacc);
             nacc = nacc2 - 32;
@@ -95,36 +98,35 @@ struct AnsBackWriter {
     __device__ __forceinline__ void maybe_flush(char *lds) {
         if (pend >= 16) {
             const char *r = lds + fa;
-            u32 w[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * THREADS * 4);
-            // memory order is the reverse of completion order: word j of this group sits at -4*(nfl + j + 1)
-            const uint4 q0 = make_uint4(w[15], w[14], w[13], w[12]), q1 = make_uint4(w[11], w[10], w[9], w[8]);
-            const uint4 q2 = make_uint4(w[7], w[6], w[5], w[4]), q3 = make_uint4(w[3], w[2], w[1], w[0]);
-            if (!HOLD_HALF_LINE) {  // register-starved callers: plain 64-byte bursts
-                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
-                p[0] = q0;
-                p[1] = q1;
-                p[2] = q2;
-                p[3] = q3;
-            } else if (have_held) {  // this group is the lower-address half of the line whose upper half is held
-                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
-                p[0] = q0;
-                p[1] = q1;
-                p[2] = q2;
-                p[3] = q3;
-                p[4] = held[0];
-                p[5] = held[1];
-                p[6] = held[2];
-                p[7] = held[3];
-                have_held = 0;
-            } else {
-                held[0] = q0;
-                held[1] = q1;
-                held[2] = q2;
-                held[3] = q3;
+            // word j of this group (completion order) sits at -4*(nfl + j + 1) in memory and in row 15 - j of the
+            // group: the 16-byte piece i (ascending addresses) is the rows 4i .. 4i+3
+#define SCL_RING_W(j) (*reinterpret_cast<const u32 *>(r + (j) * THREADS * 4))
+#define SCL_RING_Q(i) make_uint4(SCL_RING_W(4 * (i)), SCL_RING_W(4 * (i) + 1), SCL_RING_W(4 * (i) + 2), SCL_RING_W(4 * (i) + 3))
+            if (HOLD_HALF_LINE && !have_held) {
+                // upper-address half of a line: read straight into the registers that keep it until the lower half
+                // is ready (read before the branch, the words took 16 extra copies to get there)
+                held[0] = SCL_RING_Q(0);
+                held[1] = SCL_RING_Q(1);
+                held[2] = SCL_RING_Q(2);
+                held[3] = SCL_RING_Q(3);
                 have_held = 1;
+            } else {
+                const uint4 q0 = SCL_RING_Q(0), q1 = SCL_RING_Q(1), q2 = SCL_RING_Q(2), q3 = SCL_RING_Q(3);
+                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
+                p[0] = q0;
+                p[1] = q1;
+                p[2] = q2;
+                p[3] = q3;
+                if (HOLD_HALF_LINE) {  // ... and the whole line leaves as one burst
+                    p[4] = held[0];
+                    p[5] = held[1];
+                    p[6] = held[2];
+                    p[7] = held[3];
+                    have_held = 0;
+                }
             }
+#undef SCL_RING_Q
+#undef SCL_RING_W
             nfl += 16;
             pend -= 16;
             fa ^= 16 * THREADS * 4;  // the ring has two halves of 16 words
@@ -140,10 +142,10 @@ struct AnsBackWriter {
             p[3] = held[3];
         }
         u32 *end32 = reinterpret_cast<u32 *>(slot_end);
-        u32 a = fa;
+        u32 a = fa + 15 * THREADS * 4;  // the oldest word of the group sits in its top row (pend < 16 here)
         for (u32 j = 0; j < pend; ++j) {
             end32[-(i64)(nfl + j) - 1] = *ring_at(lds, a);
-            a = (a + THREADS * 4) & (RING_BYTES - 1);
+            a -= THREADS * 4;
         }
         const u32 words = nfl + pend;
         if (nacc) end32[-(i64)words - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
