@@ -155,13 +155,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     lib.require_device()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SCL_BENCH_SHARED_GPU=1 (testing the N > 1 code path on a one-GPU box): every rank uses cuda:0 and the ranks
+    # talk over gloo -- RCCL refuses two ranks on one device.  Never set for a measurement.
+    shared_gpu = os.environ.get("SCL_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
-                                device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
+                                    device_id=dev)
         world = dist.get_world_size()
 
     freq = {"t256": bench_data.t256_table, "uniform": bench_data.uniform256_table,
@@ -193,7 +200,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if shared_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
         step()
@@ -208,7 +218,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
