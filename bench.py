@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--aec-K", type=int, default=16, help="alphabet of the order-1 adaptive arithmetic coder (configs[3])")
     ap.add_argument("--aec-model", choices=["order1", "fixed"], default="order1",
                     help="arithmetic coder: order-1 adaptive model on a Markov-1 source, or FixedFreqModel(--table) on i.i.d. symbols")
+    ap.add_argument("--num-bits-out", type=int, default=1, help="rANS NUM_BITS_OUT (reference default 1)")
+    ap.add_argument("--range-factor", type=int, default=1 << 16, help="rANS RANGE_FACTOR (reference default 2^16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
     ap.add_argument("--sym-pad", type=int, default=0, help="experiment: extra bytes between input rows")
@@ -52,7 +54,8 @@ def make_model(args, freq):
     from stanford_compression_library_amd.backend import models
 
     if args.coder == "rans":
-        return models.RansModel(freq.tolist(), 1 << 16, 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1 << 16)
+        return (models.RansModel(freq.tolist(), args.range_factor, args.num_bits_out, 32),
+                dict(NUM_BITS_OUT=args.num_bits_out, RANGE_FACTOR=args.range_factor))
     if args.coder == "tans":
         return models.TansModel(freq.tolist(), 1, 32), dict(NUM_BITS_OUT=1, RANGE_FACTOR=1)
     if args.coder == "aec" and args.aec_model == "fixed":
@@ -88,8 +91,9 @@ def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
     n_probe = min(128, sym_dev.shape[0])
     sym = sym_dev[:n_probe].cpu().numpy()
     t0 = time.perf_counter()
-    streams, nbits = orc.rans_encode_batch(sym, freq)
-    orc.rans_decode_batch(streams, nbits, freq, sym.shape[1])
+    kw = dict(RF=args.range_factor, b=args.num_bits_out)
+    streams, nbits = orc.rans_encode_batch(sym, freq, **kw)
+    orc.rans_decode_batch(streams, nbits, freq, sym.shape[1], **kw)
     per_chunk = (time.perf_counter() - t0) / n_probe
     single_thread = sym.size / (per_chunk * n_probe) / 1e6
     n = int(max(n_probe, min(sym_dev.shape[0], 65536, cores * target_seconds / max(per_chunk, 1e-9))))
@@ -98,9 +102,9 @@ def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
     parts = [(bounds[i], bounds[i + 1]) for i in range(cores) if bounds[i + 1] > bounds[i]]
     with ThreadPoolExecutor(max_workers=len(parts)) as pool:
         t0 = time.perf_counter()
-        enc_parts = list(pool.map(lambda ab: orc.rans_encode_batch(sym[ab[0]:ab[1]], freq), parts))
+        enc_parts = list(pool.map(lambda ab: orc.rans_encode_batch(sym[ab[0]:ab[1]], freq, **kw), parts))
         t1 = time.perf_counter()
-        dec_parts = list(pool.map(lambda i: orc.rans_decode_batch(enc_parts[i][0], enc_parts[i][1], freq, sym.shape[1]),
+        dec_parts = list(pool.map(lambda i: orc.rans_decode_batch(enc_parts[i][0], enc_parts[i][1], freq, sym.shape[1], **kw),
                                   range(len(parts))))
         t2 = time.perf_counter()
     streams = np.concatenate([e[0] for e in enc_parts])
@@ -281,7 +285,8 @@ def main():
         # the PMC passes were taken on one workload only: never attach them to another one
         w = (traffic or {}).get("workload", {})
         if not (w.get("coder") == args.coder and w.get("table") == args.table and w.get("chunks") == args.chunks
-                and w.get("chunk_len") == args.chunk_len):
+                and w.get("chunk_len") == args.chunk_len and args.num_bits_out == 1
+                and args.range_factor == 1 << 16):
             traffic = None
 
         def roof(ms, name):

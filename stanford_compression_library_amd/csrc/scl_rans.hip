@@ -11,9 +11,11 @@
 //   * generic  : any M, NUM_BITS_OUT, RANGE_FACTOR with H < 2^63 (u32 or u64 state, real division,
 //                the reference's while-loops kept as loops).  Used for parameter sets outside the
 //                fast path; correctness first.
-//   * fast     : H < 2^31, M = 2^m <= 2^12, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r (the reference
-//                defaults with a power-of-two table, BASELINE.json configs[1]): closed-form shift
+//   * fast     : H < 2^31, any total 2 <= M <= 4096, NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r (the reference
+//                defaults, BASELINE.json configs[1]; scl_rans_fast.hip): closed-form shift
 //                count, exact reciprocal division, LDS-resident tables, slot -> symbol LUT decode.
+//   * fast, b>1: NUM_BITS_OUT in {2, 4, 8, 16}, M = 2^m <= 2^12, RANGE_FACTOR = 2^r, H < 2^31
+//                (scl_rans_fast_b.hip): same I/O, division in binary64.
 #include <string.h>
 
 #include "scl_common.h"
@@ -198,7 +200,8 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
     }
     m->dev.d_freq = m->d_freq;
     m->dev.d_cum = m->d_cum;
-    const int rc = rans_fast_build_tables(m, h_freq, cum);
+    int rc = rans_fast_build_tables(m, h_freq, cum);
+    if (rc == SCL_OK && !m->fast) rc = rans_fastb_build_tables(m, h_freq, cum);
     if (rc != SCL_OK) {
         scl_rans_model_destroy(m);
         return rc;
@@ -218,6 +221,9 @@ extern "C" void scl_rans_model_destroy(scl_rans_model *m) {
     if (m->d_cum) (void)hipFree(m->d_cum);
     if (m->d_enc_tab) (void)hipFree(m->d_enc_tab);
     if (m->d_dec_tab) (void)hipFree(m->d_dec_tab);
+    if (m->d_encb_tab) (void)hipFree(m->d_encb_tab);
+    if (m->d_encb_aux) (void)hipFree(m->d_encb_aux);
+    if (m->d_decb_tab) (void)hipFree(m->d_decb_tab);
     delete m;
 }
 
@@ -231,7 +237,7 @@ extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info)
     info->size_bits = m->dev.size_bits;
     info->num_bits_out = m->dev.b;
     info->max_bits_per_symbol = m->max_bits_per_symbol;
-    info->fast_path = m->fast;
+    info->fast_path = m->fast | m->fastb;
     return SCL_OK;
 }
 
@@ -266,6 +272,10 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
         out_stride >= scl_rans_slot_bytes(m, chunk_len))
         rans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                 d_out_bit_offset, d_out_nbits, d_status, st);
+    else if (m->fastb && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+             out_stride >= scl_rans_slot_bytes(m, chunk_len))
+        rans_fastb_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                 d_out_bit_offset, d_out_nbits, d_status, st);
     else if (m->state32)
         hipLaunchKernelGGL(rans_encode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
@@ -290,6 +300,9 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
     if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
         rans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, st);
+    else if (m->fastb && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+        rans_fastb_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                 out_cap, d_out_lens, d_consumed, d_status, st);
     else if (m->state32)
         hipLaunchKernelGGL(rans_decode_generic<u32>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,

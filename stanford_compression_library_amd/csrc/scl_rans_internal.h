@@ -27,9 +27,29 @@ struct RansFastDev {
     const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
 
+// fast path for NUM_BITS_OUT = b in {2, 4, 8, 16} (scl_rans_fast_b.hip): M a power of two <= 4096, H < 2^31
+struct RansFastBDev {
+    u32 K;
+    u32 nsb;
+    u32 size_bits;
+    u32 m_log2;
+    u32 L;
+    u32 M;
+    u32 b;
+    u32 cbl;             // 32 - bit_width(L): leading zeros of a state that needs no refill
+    const uint4 *d_enc;  // [256] {1/f as binary64 (lo, hi), thresh, cum}
+    const u32 *d_aux;    // [256] (M - f) | (b k1) << 24
+    const uint2 *d_dec;  // [M]   slot -> {f | sym << 24, slot - cum}
+};
+
 struct scl_rans_model {
     RansDev dev;
     RansFastDev fdev;
+    RansFastBDev fbdev;
+    u32 fastb;
+    uint4 *d_encb_tab;
+    u32 *d_encb_aux;
+    uint2 *d_decb_tab;
     u64 H;
     u32 max_bits_per_symbol;
     u32 state32;  // H < 2^32
@@ -48,3 +68,12 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);
+
+// scl_rans_fast_b.hip (NUM_BITS_OUT > 1)
+int rans_fastb_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum);
+void rans_fastb_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                              u32 *d_status, hipStream_t st);
+void rans_fastb_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
+                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);

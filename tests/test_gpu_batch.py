@@ -775,3 +775,45 @@ def test_cooperative_line_store_full_and_partial_waves(name, n, dev):
         o_sym, o_used = o_dec(np.packbits(bits), int(nbits[c]), freq)
         assert o_used == nbits[c] == used[c].item()
         assert np.array_equal(np.asarray(o_sym), dec[c, :lens[c]])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 16))))
+def test_random_models_num_bits_out_vs_oracle(seed, dev):
+    """NUM_BITS_OUT in {2, 4, 8, 16} (the reference's own sweep uses 8, rANS.py:366-379) on the tuned kernels of
+    scl_rans_fast_b.hip: random power-of-two tables, RANGE_FACTOR as large as H < 2^31 and RF 2^b <= 2^24 allow (or
+    small), ragged chunks, symbols from the table and from a uniform distribution; streams equal to the oracle's,
+    decode equal to the input with the exact bit count -- and the same through the any-parameter kernels."""
+    rng = np.random.default_rng(31000 + seed)
+    b = int(rng.choice([2, 4, 8, 16]))
+    K = int(rng.choice([2, 3, 5, 16, 17, 100, 255, 256]))
+    m_log2 = int(rng.integers(max(1, int(np.ceil(np.log2(K)))), 13))
+    r_max = min(24 - b, 31 - b - m_log2)
+    if r_max < 0:
+        m_log2 = 31 - b  # only for b = 16 with big tables: shrink the table instead
+        K = min(K, 1 << m_log2)
+        r_max = 0
+    r = int(rng.integers(0, r_max + 1)) if seed % 3 else r_max
+    RF = 1 << r
+    f = _random_pow2_table(rng, K, m_log2)
+    size_bits = int(rng.choice([32, 12, 20]))
+    cap = 640
+    lens = np.concatenate([[0, 1, 15, 16, 17, 127, 128, 129, 255, 256, 640], rng.integers(0, cap + 1, 29)]).astype(np.int32)
+    p = f / f.sum()
+    sym = np.stack([rng.choice(K, cap, p=p) if c % 3 else rng.integers(0, K, cap) for c in range(lens.size)]).astype(np.uint8)
+    d_sym, d_lens = torch.from_numpy(sym).to(dev), torch.from_numpy(lens).to(dev)
+    model = models.RansModel(f.tolist(), RF, b, size_bits)
+    assert model.info().fast_path, f"b={b} K={K} M=2^{m_log2} RF=2^{r}: expected the tuned kernels"
+    for generic in (False, True):
+        enc = model.encode_batch(d_sym, lens=d_lens, any_parameter_kernels=generic)
+        dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap,
+                                                      any_parameter_kernels=generic)
+        torch.cuda.synchronize()
+        assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+        data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+        dec = dec.cpu().numpy()
+        assert np.array_equal(dlens.cpu().numpy(), lens) and np.array_equal(used.cpu().numpy(), nbits)
+        for c in range(lens.size):
+            rb, rn = orc.rans_encode(sym[c, :lens[c]], f, RF=RF, b=b, size_bits=size_bits)
+            assert int(nbits[c]) == rn, f"b={b} K={K} M=2^{m_log2} RF=2^{r} chunk {c} generic={generic}"
+            assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+            assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"

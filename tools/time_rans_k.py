@@ -7,12 +7,13 @@ from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 K = int(os.environ.get("K", 64))
 M = int(os.environ.get("M", 4096))
+B = int(os.environ.get("B", 1))  # NUM_BITS_OUT
 RF = int(os.environ.get("RF", 1 << 16))  # RANGE_FACTOR (a tANS model with big tables runs as rANS with its RANGE_FACTOR)
 rng = np.random.default_rng(3)
 w = rng.dirichlet(np.ones(K)); f = np.maximum(1, np.floor((M - K) * w) + 1).astype(np.int64); f[np.argmax(f)] += M - f.sum()
 n_chunks, chunk_len = 262144, 4096
 sym = bench_data.iid_chunks_device(f, n_chunks, chunk_len, seed=9, device=dev)
-model = models.RansModel(f.tolist(), RF, 1, 32)
+model = models.RansModel(f.tolist(), RF, B, 32)
 enc = model.alloc_encoded(n_chunks, chunk_len, dev); dec = model.alloc_decoded(n_chunks, chunk_len, dev)
 for _ in range(2):
     model.encode_batch(sym, out=enc); model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec)
@@ -24,4 +25,4 @@ for _ in range(5):
     model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
     torch.cuda.synchronize(); te += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
 ok = torch.equal(dec[0][:, :chunk_len], sym)
-print(f"K={K} M={M} RF={RF}: encode {te/5:.3f} ms  decode {td/5:.3f} ms  round trip ok={ok}")
+print(f"K={K} M={M} RF={RF} b={B} fast={bool(model.info().fast_path)}: encode {te/5:.3f} ms  decode {td/5:.3f} ms  round trip ok={ok}")
