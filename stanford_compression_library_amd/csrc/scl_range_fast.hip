@@ -196,16 +196,35 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
     for (int d = 0; d < 4; ++d) {
         const u32 w = wv[d];
         const u32 a[4] = {(w << 3) & 0x7F8u, (w >> 5) & 0x7F8u, (w >> 13) & 0x7F8u, (w >> 21) & 0x7F8u};
+        // two symbols per visit of the byte accumulator: their released bytes (0..3 each in the common case) are
+        // merged first when they fit a word together -- "a word completed" is then tested, and its branch body
+        // executed by the whole wave, once per pair instead of once per symbol
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bad = max(bad, a[j]);
-            u32 bytes, nb;
-            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), md, bytes, nb);
-            o.put_bytes(lds, bytes, nb);
-            while (nb == 4 && rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
-                o.put_bytes(lds, low >> 24, 1);
-                low <<= 8;
-                range <<= 8;
+        for (int j = 0; j < 4; j += 2) {
+            bad = max(bad, max(a[j], a[j + 1]));
+            u32 b0, n0, b1, n1;
+            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), md, b0, n0);
+            if (n0 == 4) {  // rare: a full word at once; keep the reference's order of events
+                o.put_bytes(lds, b0, 4);
+                b0 = 0;
+                n0 = 0;
+                while (rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
+                    o.put_bytes(lds, low >> 24, 1);
+                    low <<= 8;
+                    range <<= 8;
+                }
+            }
+            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j + 1]), md, b1, n1);
+            if (__builtin_expect(n0 + n1 <= 4 && n1 != 4, 1)) {
+                o.put_bytes(lds, b0 | (b1 << (8 * n0)), n0 + n1);  // n0 <= 3 here
+            } else {
+                o.put_bytes(lds, b0, n0);
+                o.put_bytes(lds, b1, n1);
+                while (n1 == 4 && rg_needs_byte(low, range)) {
+                    o.put_bytes(lds, low >> 24, 1);
+                    low <<= 8;
+                    range <<= 8;
+                }
             }
         }
     }
