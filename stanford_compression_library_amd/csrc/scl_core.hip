@@ -123,6 +123,14 @@ __device__ __forceinline__ u32 cp_payload_bits(const BitReader &r, u64 q, u32 w_
     return v;
 }
 
+// The wave walks the record in 16-byte blocks ALIGNED IN THE DESTINATION (block k = bytes [16k - a, 16k - a + 16) of
+// the payload, a = payload address mod 16), four blocks per lane and trip:
+//   * an interior block (all 16 bytes inside the record, its 160 source bits inside the stream and past the lead
+//     bits) is five aligned source words funnel-shifted into one aligned 16-byte store; the loads of all four
+//     blocks are issued before the first store, so a typical 3.7 KiB record costs the wave ONE round trip to memory
+//     for its bulk (the previous version -- head bytes, words up to the first boundary, bulk loop, tail words, tail
+//     bytes, each a loop of its own waiting for its own loads -- took eleven, and a wave lived 18 us);
+//   * the bytes before the first and after the last interior block go through cp_payload_bits, one byte per lane.
 __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const u64 *__restrict__ bit_off,
                                               const u32 *__restrict__ nbits, u64 n, int mode, u8 *__restrict__ out,
                                               u64 out_capacity, const u64 *__restrict__ rec_off) {
@@ -130,10 +138,11 @@ __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const 
     const u64 c = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / SCL_WAVE;
     if (c >= n) return;
     const u64 o0 = rec_off[c], o1 = rec_off[c + 1];
-    if (o1 > out_capacity) return;  // caller sees the required size in rec_off[n]
     const u32 nb = nbits[c];
+    const u64 boff = bit_off[c];
+    if (o1 > out_capacity) return;  // caller sees the required size in rec_off[n]
     BitReader r;
-    r.init(in, ~0ull >> 1, bit_off[c], nb);  // every stream byte lies inside the caller's buffer
+    r.init(in, ~0ull >> 1, boff, nb);  // every stream byte lies inside the caller's buffer
     u8 *dst = out + o0;
     u64 rec_bytes = o1 - o0;
     u32 lead = 0, pad = 0;
@@ -150,50 +159,53 @@ __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const 
         dst += 4;
         rec_bytes -= 4;
     }
-    // unaligned head up to a 4-byte boundary of the destination, then whole words, then the tail
-    u64 head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3;
-    if (head > rec_bytes) head = rec_bytes;
-    for (u64 q = lane; q < head; q += SCL_WAVE) dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
-    const u64 n_words = (rec_bytes - head) / 4;
-    // the bulk: 16 bytes per lane and step from five aligned source words, funnel-shifted (the word-at-a-time loop
-    // below moved 1.5 TB/s).  It starts at the first 64-byte boundary of the destination past the lead bits (a quad of
-    // lanes then fills one aligned 64-byte sector: 3 % faster than starting at a 16-byte boundary) and
-    // covers every block whose 160 source bits lie inside the stream.
-    u64 w_done = 0;
+    const u32 a = (u32)(reinterpret_cast<uintptr_t>(dst) & 15);
+    u8 *dst_al = dst - a;  // block k lives at dst_al + 16 k
+    const u32 *in32 = reinterpret_cast<const u32 *>(in);
+    const i64 src_base = (i64)boff - (i64)lead - 8 * (i64)a;  // source bit of byte 0 of block 0 (may lie before the stream)
+    const i64 src_al = src_base & ~31ll;                       // ... rounded down to a word
+    const u32 sh = (u32)src_base & 31u;                        // the same for every block (128 k is a multiple of 32)
+    const i64 stream_end = (i64)boff + (i64)nb;
+    // interior blocks k_first .. k_last: inside the record, past the lead bits, five source words inside the stream
+    const i64 k_first = max((i64)((a + 15) / 16), ((i64)lead + 8 * (i64)a + 127) / 128);
+    i64 k_last = (i64)((a + rec_bytes) / 16) - 1;
     {
-        u64 pre = ((64 - (reinterpret_cast<uintptr_t>(dst + head) & 63)) & 63) / 4;  // words up to that boundary
-        if (lead && pre == 0) pre = 16;
-        const u64 q1 = head + 4 * pre;
-        const i64 room = (i64)nb + lead - 160 - 8 * (i64)q1;  // bits available beyond block 0
-        if (pre <= n_words && room >= 0 && q1 + 16 <= rec_bytes) {
-            u64 nblk = min((rec_bytes - q1) / 16, (u64)room / 128 + 1);
-            for (u64 w = lane; w < pre; w += SCL_WAVE)
-                *reinterpret_cast<u32 *>(dst + head + 4 * w) = scl_bswap32(cp_payload_bits(r, head + 4 * w, 4, lead, pad));
-            const u32 *in32 = reinterpret_cast<const u32 *>(in);
-            for (u64 k = lane; k < nblk; k += SCL_WAVE) {
-                const u64 q = q1 + 16 * k;
-                const u64 s0 = r.pos + 8 * q - lead;
-                const u32 *src = in32 + (s0 >> 5);
-                const u32 sh = (u32)s0 & 31u;
-                const u32 b0 = scl_bswap32(src[0]), b1 = scl_bswap32(src[1]), b2 = scl_bswap32(src[2]);
-                const u32 b3 = scl_bswap32(src[3]), b4 = scl_bswap32(src[4]);
-                uint4 o;  // (a << sh) | (b >> (32 - sh)); v_alignbit takes its shift modulo 32, hence the select
+        const i64 room = stream_end - 160 - src_al;
+        const i64 k_src = room >= 0 ? room / 128 : -1;
+        if (k_src < k_last) k_last = k_src;
+    }
+    const bool any_fast = k_last >= k_first;
+    const u64 q_lo = any_fast ? (u64)(16 * k_first - a) : rec_bytes;  // payload bytes [0, q_lo) and [q_hi, rec_bytes)
+    const u64 q_hi = any_fast ? (u64)(16 * (k_last + 1) - a) : rec_bytes;  // are the edges: one byte per lane
+    for (u64 q = lane; q < q_lo; q += SCL_WAVE) dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
+    for (u64 q = q_hi + lane; q < rec_bytes; q += SCL_WAVE) dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
+    for (i64 k0 = k_first; k0 <= k_last; k0 += 4 * SCL_WAVE) {
+        u32 w[4][5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 k = k0 + (i64)j * SCL_WAVE + lane;
+            if (k <= k_last) {
+                const u32 *src = in32 + ((src_al + 128 * k) >> 5);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) w[j][i] = src[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 k = k0 + (i64)j * SCL_WAVE + lane;
+            if (k <= k_last) {
+                const u32 b0 = scl_bswap32(w[j][0]), b1 = scl_bswap32(w[j][1]), b2 = scl_bswap32(w[j][2]);
+                const u32 b3 = scl_bswap32(w[j][3]), b4 = scl_bswap32(w[j][4]);
+                uint4 o;  // (x << sh) | (y >> (32 - sh)); v_alignbit takes its shift modulo 32, hence the select
                 o.x = sh ? __builtin_amdgcn_alignbit(b0, b1, 32 - sh) : b0;
                 o.y = sh ? __builtin_amdgcn_alignbit(b1, b2, 32 - sh) : b1;
                 o.z = sh ? __builtin_amdgcn_alignbit(b2, b3, 32 - sh) : b2;
                 o.w = sh ? __builtin_amdgcn_alignbit(b3, b4, 32 - sh) : b3;
                 o.x = scl_bswap32(o.x), o.y = scl_bswap32(o.y), o.z = scl_bswap32(o.z), o.w = scl_bswap32(o.w);
-                *reinterpret_cast<uint4 *>(dst + q) = o;
+                *reinterpret_cast<uint4 *>(dst_al + 16 * k) = o;
             }
-            w_done = pre + 4 * nblk;
         }
     }
-    for (u64 w = w_done + lane; w < n_words; w += SCL_WAVE) {
-        const u64 q = head + 4 * w;
-        *reinterpret_cast<u32 *>(dst + q) = scl_bswap32(cp_payload_bits(r, q, 4, lead, pad));
-    }
-    for (u64 q = head + 4 * n_words + lane; q < rec_bytes; q += SCL_WAVE)
-        dst[q] = (u8)cp_payload_bits(r, q, 1, lead, pad);
 }
 
 extern "C" uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks) {
