@@ -817,3 +817,30 @@ def test_random_models_num_bits_out_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"b={b} K={K} M=2^{m_log2} RF=2^{r} chunk {c} generic={generic}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+
+
+@pytest.mark.parametrize("framed", [False, True])
+def test_compact_long_and_tiny_streams(framed, dev):
+    """The copy kernel of scl_streams_compact walks a record in 16-byte blocks aligned in the destination, 256 per
+    trip of the wave: records of several trips (11 KiB), records shorter than one block or than the 160 source bits
+    an interior block needs, and every destination alignment (the records before them have random sizes)."""
+    make_model, o_enc, _ = CODERS["rans_default"]
+    freq = bench_data.t256_table()
+    model = make_model(freq)
+    rng = np.random.default_rng(5)
+    cap = 12000
+    lens = np.concatenate([[cap, 0, 1, 2, 3, cap - 1, 9000, 4500, 4600, 17, 18, 19, 20, 21, 22],
+                           rng.integers(0, 64, 40), rng.integers(4000, cap + 1, 12)]).astype(np.int32)
+    sym = bench_data.iid_chunks_host(freq, len(lens), cap, seed=22)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dense, offsets = models.compact(enc, framed=framed)
+    dense, offsets = dense.cpu().numpy(), offsets.cpu().numpy()
+    expect = []
+    for c in range(len(lens)):
+        rb, rn = o_enc(sym[c, :lens[c]], freq)
+        bits = np.unpackbits(rb)[:rn]
+        expect.append(_frame_reference(bits) if framed else np.packbits(bits))
+    sizes = np.array([e.size for e in expect])
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(sizes)]))
+    for c, e in enumerate(expect):
+        assert np.array_equal(dense[offsets[c]:offsets[c + 1]], e), f"record {c} (len {lens[c]})"
