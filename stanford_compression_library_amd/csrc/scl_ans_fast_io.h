@@ -35,16 +35,19 @@ struct AnsBackWriter {
     // ds_read2 pair arrived swapped and cost two copies).
     u32 ra;    // LDS byte address of the ring word that completes next (thread column, moves DOWN a row per word, wraps)
     u32 fa;    // LDS byte address of the lowest row of the oldest unflushed group of 16 words
-    u32 pend;  // completed words not yet stored to memory
     u32 nfl;   // words already stored to memory
     u8 *slot_end;
+
+    // completed words not yet stored to memory: the oldest of them sits in the top row of the group at fa, the next
+    // word goes to ra, one row lower per word (never 32 pending: see maybe_flush) -- not kept as a counter, which
+    // would cost an instruction per completed word where this costs three per flush check
+    __device__ __forceinline__ u32 pend() const { return ((fa + 15 * THREADS * 4 - ra) & (RING_BYTES - 1)) / (THREADS * 4); }
 
     __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
         lo = 0;
         nacc = 0;
         ra = tid * 4 + 31 * THREADS * 4;
         fa = tid * 4 + 16 * THREADS * 4;
-        pend = 0;
         nfl = 0;
         slot_end = slot_end_;
         have_held = 0;
@@ -63,7 +66,6 @@ struct AnsBackWriter {
         *ring_at(lds, ra) = __builtin_bswap32(lo2);
         const u32 m = 0u - (nacc2 >> 5);                 // all ones iff the word completed (nacc2 < 64)
         ra = (ra - (m & (THREADS * 4))) & (RING_BYTES - 1);
-        pend -= m;
         const u32 hi = v >> ((32 - nacc) & 31);          // only used when m != 0, which implies nacc >= 1
         lo = (hi & m) | (lo2 & ~m);
         nacc = nacc2 & 31;
@@ -71,7 +73,6 @@ struct AnsBackWriter {
         if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
             *ring_at(lds, ra) = __builtin_bswap32(lo2);
             ra = (ra - THREADS * 4) & (RING_BYTES - 1);
-            ++pend;
             lo = v >> (32 - nacc);
             nacc = nacc2 - 32;
         } else {
@@ -96,7 +97,7 @@ struct AnsBackWriter {
     u32 have_held;
 
     __device__ __forceinline__ void maybe_flush(char *lds) {
-        if (pend >= 16) {
+        if (pend() >= 16) {
             const char *r = lds + fa;
             // word j of this group (completion order) sits at -4*(nfl + j + 1) in memory and in row 15 - j of the
             // group: the 16-byte piece i (ascending addresses) is the rows 4i .. 4i+3
@@ -128,7 +129,6 @@ struct AnsBackWriter {
 #undef SCL_RING_Q
 #undef SCL_RING_W
             nfl += 16;
-            pend -= 16;
             fa ^= 16 * THREADS * 4;  // the ring has two halves of 16 words
         }
     }
@@ -142,12 +142,13 @@ struct AnsBackWriter {
             p[3] = held[3];
         }
         u32 *end32 = reinterpret_cast<u32 *>(slot_end);
-        u32 a = fa + 15 * THREADS * 4;  // the oldest word of the group sits in its top row (pend < 16 here)
-        for (u32 j = 0; j < pend; ++j) {
+        u32 a = fa + 15 * THREADS * 4;  // the oldest word of the group sits in its top row (fewer than 16 pending here)
+        const u32 np = pend();
+        for (u32 j = 0; j < np; ++j) {
             end32[-(i64)(nfl + j) - 1] = *ring_at(lds, a);
             a -= THREADS * 4;
         }
-        const u32 words = nfl + pend;
+        const u32 words = nfl + np;
         if (nacc) end32[-(i64)words - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
         return (u64)words * 32 + nacc;
     }
