@@ -844,3 +844,30 @@ def test_compact_long_and_tiny_streams(framed, dev):
     assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(sizes)]))
     for c, e in enumerate(expect):
         assert np.array_equal(dense[offsets[c]:offsets[c + 1]], e), f"record {c} (len {lens[c]})"
+
+
+def test_status_reporting_num_bits_out_kernels(dev):
+    """scl_rans_fast_b.hip: a symbol outside the alphabet is flagged (KeyError in the reference), the other chunks
+    are untouched, and a corrupted stream ends in a status bit, never in a crash."""
+    freq = bench_data.t256_table()[:64].copy()
+    freq[0] += 4096 - freq.sum()
+    model = models.RansModel(freq.tolist(), 1 << 8, 8, 32)
+    assert model.info().fast_path
+    rng = np.random.default_rng(3)
+    sym = rng.integers(0, 64, (130, 300)).astype(np.uint8)
+    sym[77, 123] = 64  # first symbol index outside the alphabet
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev))
+    torch.cuda.synchronize()
+    st = enc.status.cpu().numpy()
+    assert st[77] & backend_lib.ST_SYMBOL and int(np.abs(np.delete(st, 77)).sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in (0, 76, 78, 129):
+        rb, rn = orc.rans_encode(sym[c], freq, RF=1 << 8, b=8)
+        assert rn == nbits[c] and np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn])
+    byte = int(enc.bit_offset[5].item()) // 8 + 11
+    enc.data[byte] ^= 0xA5
+    _, _, _, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, 300)
+    torch.cuda.synchronize()
+    status = status.cpu().numpy()
+    assert int(status[5]) & (backend_lib.ST_STATE | backend_lib.ST_TRUNCATED)
+    assert int(np.abs(np.delete(status, [5, 77])).sum()) == 0
