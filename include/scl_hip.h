@@ -88,7 +88,9 @@ typedef struct scl_rans_info {
     uint32_t size_bits;      /* DATA_BLOCK_SIZE_BITS                                             */
     uint32_t num_bits_out;   /* NUM_BITS_OUT                                                     */
     uint32_t max_bits_per_symbol; /* worst-case field width, for slot sizing                     */
-    uint32_t fast_path;      /* 1 if the u32 / power-of-two-M / b=1 kernels serve this model      */
+    uint32_t fast_path;      /* 1 if tuned kernels serve this model: u32 state with NUM_BITS_OUT = 1
+                                and any total <= 4096, or NUM_BITS_OUT in {2,4,8,16} with a
+                                power-of-two total <= 4096 (RANGE_FACTOR a power of two)        */
 } scl_rans_info;
 
 /* rANSParams(freqs, DATA_BLOCK_SIZE_BITS, NUM_BITS_OUT, RANGE_FACTOR) -> device-resident tables.
