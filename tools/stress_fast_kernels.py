@@ -9,7 +9,7 @@ from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 n_chunks, chunk_len = int(os.environ.get("NCHUNKS", 262144)), 4096
 mode = os.environ.get("MODEL", "fixed")
-if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "rans_m3000", "fixed_k64"):
+if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "rans_m3000", "fixed_k64", "rans_b8"):
     freq = bench_data.t256_table()
     if mode in ("rans_k64", "rans_k200", "fixed_k64"):  # alphabets below 256: the symbol-checking encoder variants
         K = 64 if mode.endswith("k64") else 200
@@ -25,6 +25,7 @@ if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "r
              "rans_k64": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
              "rans_k200": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
              "rans_m3000": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "rans_b8": lambda: models.RansModel(freq.tolist(), 1 << 8, 8, 32),  # NUM_BITS_OUT = 8 kernels
              "fixed_k64": lambda: models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
              "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
              "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
