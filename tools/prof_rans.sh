@@ -6,8 +6,11 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof
 RAW=/tmp/prof_raw
 rm -rf $RAW; mkdir -p $OUT $RAW
+# the kernel trace runs bench.py's default step counts (50 timed after 20 warm-up: the durations it reports are the ones
+# bench.py prints); the counter passes only need a few dispatches
+TRACE_CMD="python $REPO/bench.py --no-cpu-baseline ${BENCH_ARGS}"
 CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $TRACE_CMD > $OUT/trace.log 2>&1
 find $RAW/trace -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find $RAW/trace -name '*kernel_trace.csv' -exec python3 $REPO/tools/summarize_trace.py {} $OUT/kernel_trace_summary.txt \;
 # PMC passes, each in its own run (never combined with tracing)
