@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const 
                 o.z = sh ? __builtin_amdgcn_alignbit(b2, b3, 32 - sh) : b2;
                 o.w = sh ? __builtin_amdgcn_alignbit(b3, b4, 32 - sh) : b3;
                 o.x = scl_bswap32(o.x), o.y = scl_bswap32(o.y), o.z = scl_bswap32(o.z), o.w = scl_bswap32(o.w);
-                *reinterpret_cast<uint4 *>(dst_al + 16 * k) = o;
+                typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
+                const u32x4_nt t = {o.x, o.y, o.z, o.w};  // written once, whole sectors per quad of lanes
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(dst_al + 16 * k));
             }
         }
     }
