@@ -90,3 +90,31 @@ def test_histogram_equals_get_counts():
         ref = DataBlock(data.tolist()).get_counts() if n else {}
         assert got.sum() == n and all(got[s] == c for s, c in ref.items())
         assert np.array_equal(got, np.bincount(data, minlength=256))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 code path (per-rank shards and seeds, barriers, max-over-ranks timing, rank-0 JSON line) run as
+    two torch.distributed ranks that share cuda:0 and talk over gloo (SCL_BENCH_SHARED_GPU=1; RCCL refuses two ranks on
+    one device, and the GPU box has one)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SCL_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--chunks", "4096", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
+    assert out["value"] > 0 and out["config"]["chunks_per_gpu"] == 4096
