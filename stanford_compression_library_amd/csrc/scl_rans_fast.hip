@@ -211,9 +211,11 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
 //           (4 back-to-back 16-byte stores), end of the chunk first.
 // One workgroup of 1024 lanes per CU: [0, 128 KiB) word ring, [128 KiB, 160 KiB) slot table of 8-byte entries
 // {f | sym << 24, slot - c}: v_mad_u32_u24 ignores the symbol byte, so no field needs extracting.
+// Workgroup size: 1024 lanes (one workgroup per CU, 4 waves per SIMD) for batches that fill the chip that way
+// (>= 256 workgroups); smaller batches take 256-lane workgroups so that they spread over all CUs instead of running 4
+// waves per SIMD on a quarter of them (65 536 chunks: decode 0.48 -> see DESIGN.md).
 #define RD_THREADS 1024
-#define RD_RING_BYTES (32 * RD_THREADS * 4)
-typedef AnsBitReader<RD_THREADS> DecIn;
+#define RD_THREADS_SMALL 256
 
 // decode one symbol: state update + renormalisation from the 32-bit lookahead `lk` (bits are consumed from
 // its top); returns the first table word (symbol in byte 3) and the number of bits used.
@@ -264,7 +266,7 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
 }
 
 // 16 symbols, last first, into one 16-byte register (byte i of the result = symbol i of the block)
-template <int ML_T, int CB_T>
+template <int ML_T, int CB_T, typename DecIn>
 __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt,
                                              const RfGenM &rf_gen) {
     u32 ow[4];
@@ -290,8 +292,8 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-template <int ML_T, int CB_T>
-__global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
+template <int ML_T, int CB_T, int THREADS>
+__global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
                                                                      const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -301,14 +303,15 @@ __global__ void __launch_bounds__(RD_THREADS) rans_decode_fast_kernel(RansFastDe
                                                                      u32 *__restrict__ status) {
     // slot table first: its offsets (< 32 KiB) then need no base added (a DS offset field reaches 64 KiB); the ring
     // works on addresses relative to its own base, which the DS offset field supplies
-    __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + RD_RING_BYTES];
+    typedef AnsBitReader<THREADS> DecIn;
+    __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + DecIn::RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
     const u32 M = P.M;
-    for (u32 i = threadIdx.x; i < M; i += RD_THREADS)
+    for (u32 i = threadIdx.x; i < M; i += THREADS)
         reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec_tab[i];
     __syncthreads();
-    const u64 c = (u64)blockIdx.x * RD_THREADS + threadIdx.x;
+    const u64 c = (u64)blockIdx.x * THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 avail = in_nbits[c];
     u32 st = 0;
@@ -473,18 +476,19 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
-    const u32 blocks = (u32)((n_chunks + RD_THREADS - 1) / RD_THREADS);
+#define RF_LAUNCH_DEC(ML, CB, TH)                                                                                  \
+    hipLaunchKernelGGL((rans_decode_fast_kernel<ML, CB, TH>), dim3((u32)((n_chunks + TH - 1) / TH)), dim3(TH), 0, st, \
+                       m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,   \
+                       d_out_lens, d_consumed, d_status)
+    // up to 2 x 256 small workgroups are resident at once (64 KiB of LDS each): beyond that the 1024-lane form wins
+    const bool big = n_chunks > 2ull * 256 * RD_THREADS_SMALL;
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
-    if (m->fdev.m_log2 == 0xFFFFFFFFu)  // total is not a power of two
-        hipLaunchKernelGGL((rans_decode_fast_kernel<-1, 0>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
-                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status);
-    else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29)
-        hipLaunchKernelGGL((rans_decode_fast_kernel<12, 3>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
-                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status);
-    else
-        hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0>), dim3(blocks), dim3(RD_THREADS), 0, st, m->fdev, d_in,
-                           in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status);
+    if (m->fdev.m_log2 == 0xFFFFFFFFu) {  // total is not a power of two
+        if (big) RF_LAUNCH_DEC(-1, 0, RD_THREADS); else RF_LAUNCH_DEC(-1, 0, RD_THREADS_SMALL);
+    } else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29) {
+        if (big) RF_LAUNCH_DEC(12, 3, RD_THREADS); else RF_LAUNCH_DEC(12, 3, RD_THREADS_SMALL);
+    } else {
+        if (big) RF_LAUNCH_DEC(0, 0, RD_THREADS); else RF_LAUNCH_DEC(0, 0, RD_THREADS_SMALL);
+    }
+#undef RF_LAUNCH_DEC
 }

@@ -22,9 +22,8 @@
 #define RB_THREADS 256
 #define RB_RING_BYTES (32 * RB_THREADS * 4)
 typedef AnsBackWriter<RB_THREADS> EncOutB;
-#define RBD_THREADS 1024
-#define RBD_RING_BYTES (32 * RBD_THREADS * 4)
-typedef AnsBitReader<RBD_THREADS> DecInB;
+#define RBD_THREADS 1024      // batches that fill the chip with one 1024-lane workgroup per CU
+#define RBD_THREADS_SMALL 256  // smaller ones spread over all CUs instead (see scl_rans_fast.hip)
 
 // ---------------------------------------------------------------------------------------------------
 // encode
@@ -122,6 +121,7 @@ __global__ void __launch_bounds__(RB_THREADS, 4) rans_encode_fastb_kernel(RansFa
 // decode
 // ---------------------------------------------------------------------------------------------------
 // One workgroup of 1024 lanes per CU: slot table {f | sym << 24, slot - c} at LDS offset 0 (32 KiB), word ring behind it.
+template <typename DecInB>
 __device__ __forceinline__ u32 rb_decode_symbol(u32 &x, DecInB &r, char *lds, const char *tab, u32 m_log2, u32 cbl,
                                                 u32 bm1) {
     const uint2 e = *reinterpret_cast<const uint2 *>(tab + ((x << 3) & (((1u << m_log2) - 1u) << 3)));
@@ -134,6 +134,7 @@ __device__ __forceinline__ u32 rb_decode_symbol(u32 &x, DecInB &r, char *lds, co
     return e.x;
 }
 
+template <typename DecInB>
 __device__ __forceinline__ uint4 rb_decode16(u32 &x, DecInB &r, char *lds, const char *tab, u32 m_log2, u32 cbl,
                                              u32 bm1) {
     u32 ow[4];
@@ -152,7 +153,8 @@ __device__ __forceinline__ uint4 rb_decode16(u32 &x, DecInB &r, char *lds, const
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-__global__ void __launch_bounds__(RBD_THREADS) rans_decode_fastb_kernel(RansFastBDev P, const u8 *__restrict__ in,
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) rans_decode_fastb_kernel(RansFastBDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,
                                                                        const u64 *__restrict__ bit_off,
                                                                        const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -160,12 +162,13 @@ __global__ void __launch_bounds__(RBD_THREADS) rans_decode_fastb_kernel(RansFast
                                                                        u32 out_cap, u32 *__restrict__ out_lens,
                                                                        u32 *__restrict__ consumed,
                                                                        u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + RBD_RING_BYTES];
+    typedef AnsBitReader<THREADS> DecInB;
+    __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + DecInB::RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
-    for (u32 i = threadIdx.x; i < P.M; i += RBD_THREADS) reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec[i];
+    for (u32 i = threadIdx.x; i < P.M; i += THREADS) reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec[i];
     __syncthreads();
-    const u64 c = (u64)blockIdx.x * RBD_THREADS + threadIdx.x;
+    const u64 c = (u64)blockIdx.x * THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 avail = in_nbits[c];
     u32 st = 0;
@@ -303,8 +306,13 @@ void rans_fastb_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_
 void rans_fastb_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
-    const u32 blocks = (u32)((n_chunks + RBD_THREADS - 1) / RBD_THREADS);
-    hipLaunchKernelGGL(rans_decode_fastb_kernel, dim3(blocks), dim3(RBD_THREADS), 0, st, m->fbdev, d_in,
-                       in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                       d_consumed, d_status);
+    if (n_chunks > 2ull * 256 * RBD_THREADS_SMALL)  // more than two 256-lane workgroups per CU: the 1024-lane form
+        hipLaunchKernelGGL((rans_decode_fastb_kernel<RBD_THREADS>), dim3((u32)((n_chunks + RBD_THREADS - 1) / RBD_THREADS)),
+                           dim3(RBD_THREADS), 0, st, m->fbdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks,
+                           d_out_sym, out_stride, out_cap, d_out_lens, d_consumed, d_status);
+    else
+        hipLaunchKernelGGL((rans_decode_fastb_kernel<RBD_THREADS_SMALL>),
+                           dim3((u32)((n_chunks + RBD_THREADS_SMALL - 1) / RBD_THREADS_SMALL)), dim3(RBD_THREADS_SMALL), 0,
+                           st, m->fbdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                           out_cap, d_out_lens, d_consumed, d_status);
 }
