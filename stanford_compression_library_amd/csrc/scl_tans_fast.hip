@@ -13,10 +13,10 @@
 #include "scl_ans_fast_io.h"
 #include "scl_tans_internal.h"
 
+// Workgroup size: 1024 lanes (one workgroup per CU, tables staged once) for batches that fill the chip that way;
+// batches of up to 131 072 chunks take 256-lane workgroups so that they spread over all CUs (see scl_rans_fast.hip).
 #define TF_THREADS 1024
-#define TF_RING_BYTES (32 * TF_THREADS * 4)
-typedef AnsBackWriter<TF_THREADS, false> TfOut;  // 1024 lanes per workgroup leave 128 VGPRs: no room to hold half a line
-typedef AnsBitReader<TF_THREADS> TfIn;
+#define TF_THREADS_SMALL 256
 
 struct TfSym {
     u32 bits, k;
@@ -34,6 +34,7 @@ __device__ __forceinline__ TfSym tf_encode_symbol(u32 &x, u32 addr, const char *
     return r;
 }
 
+template <typename TfOut>
 __device__ __forceinline__ void tf_encode16(const uint4 v, u32 &x, TfOut &o, u32 &bad, char *lds, const char *sym_tab) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -50,7 +51,8 @@ __device__ __forceinline__ void tf_encode16(const uint4 v, u32 &x, TfOut &o, u32
     }
 }
 
-__global__ void __launch_bounds__(TF_THREADS) tans_encode_fast_kernel(TansFastDev P, const u8 *__restrict__ sym,
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tans_encode_fast_kernel(TansFastDev P, const u8 *__restrict__ sym,
                                                                      u64 sym_stride, const u32 *__restrict__ lens,
                                                                      u32 chunk_len, u64 n_chunks,
                                                                      u8 *__restrict__ out, u64 out_stride,
@@ -58,14 +60,21 @@ __global__ void __launch_bounds__(TF_THREADS) tans_encode_fast_kernel(TansFastDe
                                                                      u32 *__restrict__ out_nbits,
                                                                      u32 *__restrict__ status) {
     // [0,128K) word ring | [128K,132K) per-symbol table | [132K,148K) encode table (u16)
+    // the 1024-lane form leaves 128 VGPRs per lane: no room to hold half a line there
+    typedef AnsBackWriter<THREADS, (THREADS <= 256)> TfOut;
+    constexpr u32 TF_RING_BYTES = TfOut::RING_BYTES;
     __shared__ __attribute__((aligned(16))) char s_lds[TF_RING_BYTES + 4096 + 8192 * 2];
     char *lds = s_lds;
     const char *sym_tab = s_lds + TF_RING_BYTES;
-    if (threadIdx.x < 256) reinterpret_cast<uint4 *>(s_lds + TF_RING_BYTES)[threadIdx.x] = P.d_enc_sym[threadIdx.x];
-    for (u32 i = threadIdx.x; i < P.L; i += TF_THREADS)
+    if (threadIdx.x < 256) {  // row offsets are stored relative to the step table: make them LDS addresses
+        uint4 e = P.d_enc_sym[threadIdx.x];
+        e.y += TF_RING_BYTES + 4096;
+        reinterpret_cast<uint4 *>(s_lds + TF_RING_BYTES)[threadIdx.x] = e;
+    }
+    for (u32 i = threadIdx.x; i < P.L; i += THREADS)
         reinterpret_cast<u16 *>(s_lds + TF_RING_BYTES + 4096)[i] = P.d_enc_tab[i];
     __syncthreads();
-    const u64 c = (u64)blockIdx.x * TF_THREADS + threadIdx.x;
+    const u64 c = (u64)blockIdx.x * THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
@@ -130,6 +139,7 @@ __device__ __forceinline__ u32 tf_decode_symbol(u32 &x, u32 lk, u32 &used, const
     return e;
 }
 
+template <typename TfIn>
 __device__ __forceinline__ uint4 tf_decode16(u32 &x, TfIn &r, char *lds, const char *tab, u32 idx_mask, u32 cb) {
     u32 ow[4];
 #pragma unroll
@@ -152,7 +162,8 @@ __device__ __forceinline__ uint4 tf_decode16(u32 &x, TfIn &r, char *lds, const c
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-__global__ void __launch_bounds__(TF_THREADS) tans_decode_fast_kernel(TansFastDev P, const u8 *__restrict__ in,
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tans_decode_fast_kernel(TansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
                                                                      const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -160,13 +171,15 @@ __global__ void __launch_bounds__(TF_THREADS) tans_decode_fast_kernel(TansFastDe
                                                                      u32 out_cap, u32 *__restrict__ out_lens,
                                                                      u32 *__restrict__ consumed,
                                                                      u32 *__restrict__ status) {
+    typedef AnsBitReader<THREADS> TfIn;
+    constexpr u32 TF_RING_BYTES = TfIn::RING_BYTES;
     __shared__ __attribute__((aligned(16))) char s_lds[TF_RING_BYTES + 8192 * 4];
     char *lds = s_lds;
     const char *tab = s_lds + TF_RING_BYTES;
-    for (u32 i = threadIdx.x; i < P.L; i += TF_THREADS)
+    for (u32 i = threadIdx.x; i < P.L; i += THREADS)
         reinterpret_cast<u32 *>(s_lds + TF_RING_BYTES)[i] = P.d_dec_tab[i];
     __syncthreads();
-    const u64 c = (u64)blockIdx.x * TF_THREADS + threadIdx.x;
+    const u64 c = (u64)blockIdx.x * THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 avail = in_nbits[c];
     u32 st = 0;
@@ -247,9 +260,10 @@ int tans_fast_build_tables(scl_tans_model *m, const u32 *h_freq, const u32 *h_cu
     std::vector<u32> fdec(L);
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;
-        // row of symbol s starts at entry RF*c[s] and is indexed by x_shrunk - RF*f[s]; as a byte offset from
-        // LDS address 0 (ring, per-symbol table, then this table): base + 2*(RF*c - RF*f)
-        const i64 row = (i64)TF_RING_BYTES + 4096 + 2 * ((i64)D.RF * h_cum[src] - (i64)D.RF * h_freq[src]);
+        // row of symbol s starts at entry RF*c[s] and is indexed by x_shrunk - RF*f[s]; as a byte offset from the
+        // start of the step table, 2*(RF*c - RF*f) (may be negative: u32 wrap-around); the kernel adds the table's
+        // LDS address (ring size + per-symbol table) when it stages the entries
+        const i64 row = 2 * ((i64)D.RF * h_cum[src] - (i64)D.RF * h_freq[src]);
         fsym[s] = make_uint4(thresh[src], (u32)row, nbits[src] + 1, 0);
     }
     for (u32 i = 0; i < L; ++i) {
@@ -280,16 +294,27 @@ int tans_fast_build_tables(scl_tans_model *m, const u32 *h_freq, const u32 *h_cu
 void tans_fast_encode_launch(const scl_tans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
-    const u32 blocks = (u32)((n_chunks + TF_THREADS - 1) / TF_THREADS);
-    hipLaunchKernelGGL(tans_encode_fast_kernel, dim3(blocks), dim3(TF_THREADS), 0, st, m->fdev, d_sym, sym_stride,
-                       d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+    if (n_chunks > 2ull * 256 * TF_THREADS_SMALL)
+        hipLaunchKernelGGL((tans_encode_fast_kernel<TF_THREADS>), dim3((u32)((n_chunks + TF_THREADS - 1) / TF_THREADS)),
+                           dim3(TF_THREADS), 0, st, m->fdev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out,
+                           out_stride, d_bit_off, d_nbits, d_status);
+    else
+        hipLaunchKernelGGL((tans_encode_fast_kernel<TF_THREADS_SMALL>),
+                           dim3((u32)((n_chunks + TF_THREADS_SMALL - 1) / TF_THREADS_SMALL)), dim3(TF_THREADS_SMALL), 0, st,
+                           m->fdev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off,
+                           d_nbits, d_status);
 }
 
 void tans_fast_decode_launch(const scl_tans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
-    const u32 blocks = (u32)((n_chunks + TF_THREADS - 1) / TF_THREADS);
-    hipLaunchKernelGGL(tans_decode_fast_kernel, dim3(blocks), dim3(TF_THREADS), 0, st, m->fdev, d_in, in_size_bytes,
-                       d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
-                       d_status);
+    if (n_chunks > 2ull * 256 * TF_THREADS_SMALL)
+        hipLaunchKernelGGL((tans_decode_fast_kernel<TF_THREADS>), dim3((u32)((n_chunks + TF_THREADS - 1) / TF_THREADS)),
+                           dim3(TF_THREADS), 0, st, m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks,
+                           d_out_sym, out_stride, out_cap, d_out_lens, d_consumed, d_status);
+    else
+        hipLaunchKernelGGL((tans_decode_fast_kernel<TF_THREADS_SMALL>),
+                           dim3((u32)((n_chunks + TF_THREADS_SMALL - 1) / TF_THREADS_SMALL)), dim3(TF_THREADS_SMALL), 0, st,
+                           m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                           d_out_lens, d_consumed, d_status);
 }
