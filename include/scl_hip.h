@@ -173,8 +173,8 @@ typedef struct scl_aec_model scl_aec_model;
 #define SCL_MODEL_IID 1    /* AdaptiveIIDFreqModel    probability_models.py:70-92               */
 #define SCL_MODEL_ORDERK 2 /* AdaptiveOrderKFreqModel probability_models.py:95-160              */
 
-/* Every chunk starts from a FRESH copy of the model (the reference keeps model state across
-   encode_block calls of one object, quirk Q4; one chunk == one new encoder object).
+/* scl_aec_*_batch: every chunk starts from a FRESH copy of the model (one chunk == one new encoder
+   object); coder objects that live across blocks (quirk Q4) use the *_resume entry points below.
    h_freq_init: initial frequencies [K] for FIXED / IID (ignored for ORDERK, which starts from
    all-ones counts).  order_k: context length for ORDERK (0..3).  max_total: the model's
    max_allowed_total_freq.  precision 8..32. */
@@ -200,6 +200,41 @@ int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in, uint64_t i
                          uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
                          uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes,
                          void *stream);
+
+/* ---- coder objects that live across blocks (quirk Q4) ----------------------------------------
+ * The reference's ArithmeticEncoder / ArithmeticDecoder own their freq_model and never reset it
+ * (arithmetic_coding.py:52-56,118), so DataEncoder.encode (core/data_encoder_decoder.py:57-69) codes
+ * block i+1 with the counts and the order-k context block i left behind.  The *_resume entry points
+ * reproduce that: chunk c of the call CONTINUES coder c of a caller-owned device state buffer
+ * (scl_aec_state_bytes(m, n_coders) bytes, 256-byte aligned) and leaves the advanced state there.
+ * They run the any-parameter kernels.  FIXED models have nothing to carry and forward to the
+ * plain entry points (d_state may be NULL).
+ *
+ * Canonical host form of one coder's state (upload / download / *_host_resume):
+ *   h_counts : scl_aec_state_counts(m) actual counts -- IID: [K] = freqs_current.freq_list;
+ *              ORDERK: [K^(k+1)] row-major, last axis = next symbol = freqs_kplus1_tuple.ravel()
+ *              (probability_models.py:110);
+ *   h_past_k : the last k symbol indices, oldest first = past_k (probability_models.py:116). */
+uint64_t scl_aec_state_bytes(const scl_aec_model *m, uint64_t n_coders);
+uint64_t scl_aec_state_counts(const scl_aec_model *m);
+/* all n_coders coders = freshly constructed models */
+int scl_aec_state_reset(const scl_aec_model *m, void *d_state, uint64_t state_bytes, uint64_t n_coders,
+                        void *stream);
+/* one coder's state from / to the canonical host form; both synchronise `stream` */
+int scl_aec_state_upload(const scl_aec_model *m, void *d_state, uint64_t n_coders, uint64_t coder,
+                         const uint32_t *h_counts, const uint32_t *h_past_k, void *stream);
+int scl_aec_state_download(const scl_aec_model *m, const void *d_state, uint64_t n_coders, uint64_t coder,
+                           uint32_t *h_counts, uint32_t *h_past_k, void *stream);
+int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
+                                uint64_t state_bytes, void *stream);
+int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                uint32_t *d_status, void *d_state, uint64_t state_bytes, void *stream);
 
 /* ---- stream compaction / framing ------------------------------------------------------------ */
 #define SCL_COMPACT_DENSE 0  /* stream c left-aligned at byte d_out_byte_offset[c], zero tail   */
@@ -241,6 +276,15 @@ int scl_aec_encode_host(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n
                         uint64_t out_cap_bytes, uint64_t *nbits);
 int scl_aec_decode_host(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
                         uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+/* one block of a coder whose state the caller keeps on the host between calls (h_counts / h_past_k are
+   read before and rewritten after the block): ArithmeticEncoder.encode_block / ArithmeticDecoder.decode_block
+   on an object that has coded blocks before (arithmetic_coding.py:52-56) */
+int scl_aec_encode_host_resume(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                               uint64_t out_cap_bytes, uint64_t *nbits, uint32_t *h_counts,
+                               uint32_t *h_past_k);
+int scl_aec_decode_host_resume(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                               uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed,
+                               uint32_t *h_counts, uint32_t *h_past_k);
 /* peek the DATA_BLOCK_SIZE_BITS header of a host stream (so callers can size h_out_sym) */
 int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
                                uint64_t *n_out);

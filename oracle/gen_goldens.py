@@ -9,11 +9,14 @@ It imports ``scl`` (reference), encodes/decodes seeded inputs with the reference
 Encoder/Decoder classes and stores *data only*: parameters, input symbol indices, the packed
 output bits, their length, and ``num_bits_consumed`` for 0 / 3 / 61 stored trailing garbage bits.
 The fixtures pin oracle/scl_oracle.c (tests/test_oracle_goldens.py) and, through it and directly,
-the HIP kernels (tests/test_gpu_goldens.py).  Groups follow SURVEY.md section 8c (G1..G8).
+the HIP kernels (tests/test_gpu_goldens.py).  Groups follow SURVEY.md section 8c (G1..G8); G9 / G10 (golden_stream.npz) are the reference's block loop
+(multi-block streams with ONE coder object, encode_file) and its EncodedBlockWriter framing.
 """
 import copy
 import json
+import os
 import sys
+import tempfile
 
 import numpy as np
 
@@ -27,6 +30,8 @@ from scl.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEnc
 from scl.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
 from scl.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
 from scl.core.data_block import DataBlock
+from scl.core.data_stream import ListDataStream
+from scl.core.encoded_stream import EncodedBlockReader, EncodedBlockWriter
 from scl.core.prob_dist import Frequencies
 from scl.utils.bitarray_utils import BitArray
 from scl.utils.test_utils import get_random_data_block
@@ -340,8 +345,150 @@ def gen_aec(col, rng):
                        lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
 
 
+# ------------------------------------------------------------------------------------------------
+# G9 / G10: the block loop and the on-disk framing, generated by the reference's own
+# DataEncoder.encode / encode_file (core/data_encoder_decoder.py:43-86) and EncodedBlockWriter
+# (core/encoded_stream.py:137-175).  Every coder object is used for ALL blocks of its stream, so the
+# adaptive arithmetic-coder models carry their state from block to block (quirk Q4).
+def model_state(freq_model):
+    """(counts row-major, past_k) of a reference freq model, for checking the host mirror afterwards"""
+    if isinstance(freq_model, AdaptiveOrderKFreqModel):
+        return np.asarray(freq_model.freqs_kplus1_tuple, dtype=np.int64).ravel(), list(freq_model.past_k)
+    return np.asarray(freq_model.freqs_current.freq_list, dtype=np.int64), []
+
+
+class _Sink:
+    """output stream for DataDecoder.decode: the reference's ListDataStream.write_symbol never advances its
+    position, so it cannot collect more than one symbol"""
+
+    def __init__(self):
+        self.data = []
+
+    def write_block(self, block):
+        self.data.extend(block.data_list)
+
+
+def add_stream_case(col, kind, meta, alphabet, idx_syms, block_size, make_encoder, make_decoder, tmp):
+    data = [alphabet[i] for i in idx_syms]
+    path = os.path.join(tmp, "enc.bin")
+    encoder = make_encoder()
+    with EncodedBlockWriter(path) as writer:
+        encoder.encode(ListDataStream(data), block_size=block_size, encode_writer=writer)
+    file_bytes = np.fromfile(path, dtype=np.uint8)
+    # the same blocks once more through encode_block on a second object: per-block streams
+    enc2 = make_encoder()
+    block_bits = [enc2.encode_block(DataBlock(data[i:i + block_size])) for i in range(0, len(data), block_size)]
+    with EncodedBlockReader(path) as reader:
+        for bits in block_bits:
+            assert reader.get_block() == bits
+        assert reader.get_block() is None
+    # decode with ONE decoder object through the reference's loop
+    decoder = make_decoder()
+    sink = _Sink()
+    with EncodedBlockReader(path) as reader:
+        decoder.decode(reader, sink)
+    assert sink.data == data, "reference stream round trip failed"
+    arrays = dict(sym=np.asarray(idx_syms, dtype=np.uint8), file=file_bytes,
+                  block_nbits=np.asarray([len(b) for b in block_bits], dtype=np.int64),
+                  block_out=np.concatenate([pack(b)[0] for b in block_bits]) if block_bits else np.zeros(0, np.uint8))
+    meta = dict(meta, kind=kind, n=len(idx_syms), block_size=block_size)
+    if kind == "aec":
+        for tag, obj in (("enc", encoder), ("dec", decoder)):
+            counts, past = model_state(obj.freq_model)
+            arrays[f"{tag}_counts"] = counts
+            arrays[f"{tag}_past_k"] = np.asarray(past, dtype=np.int64)
+    col.add(meta, **arrays)
+
+
+def gen_stream(col, rng):
+    tmp = tempfile.mkdtemp()
+    # G10: EncodedBlockWriter on bare bit strings of awkward lengths (incl. empty and byte multiples)
+    lens = [0, 1, 5, 7, 8, 13, 16, 61, 64, 1000, 3, 2045]
+    blocks = [BitArray("".join(str(int(b)) for b in rng.integers(0, 2, n))) for n in lens]
+    path = os.path.join(tmp, "framing.bin")
+    with EncodedBlockWriter(path) as writer:
+        for b in blocks:
+            writer.write_block(b)
+    with EncodedBlockReader(path) as reader:
+        for b in blocks:
+            assert reader.get_block() == b
+    col.add(dict(kind="framing", group="G10"), file=np.fromfile(path, dtype=np.uint8),
+            block_nbits=np.asarray(lens, dtype=np.int64), block_out=np.concatenate([pack(b)[0] for b in blocks]))
+
+    # G9: three-block streams (last block partial) through encode()/decode()
+    fl = [34, 35, 546, 1, 13, 245]
+    alphabet = list("ABCDEF")
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    syms = iid_indices(fl, 2500, seed=9)
+    rp = rANSParams(fr)
+    add_stream_case(col, "rans", dict(group="G9", freq=fl, RF=rp.RANGE_FACTOR, b=1, size_bits=32), alphabet, syms, 1000,
+                    lambda: rANSEncoder(rp), lambda: rANSDecoder(rp), tmp)
+    fl2 = [3, 4, 9]
+    fr2 = Frequencies(dict(zip("ABC", fl2)))
+    tp = tANSParams(fr2, RANGE_FACTOR=1 << 4)
+    add_stream_case(col, "tans", dict(group="G9", freq=fl2, RF=tp.RANGE_FACTOR, size_bits=32), list("ABC"),
+                    iid_indices(fl2, 2500, seed=9), 1000, lambda: tANSEncoder(tp), lambda: tANSDecoder(tp), tmp)
+    gp = RangeCoderParams()
+    add_stream_case(col, "range", dict(group="G9", freq=fl, precision=32, size_bits=32), alphabet, syms, 1000,
+                    lambda: RangeEncoder(gp, fr), lambda: RangeDecoder(gp, fr), tmp)
+    # arithmetic coder: the model object lives across the blocks
+    p = AECParams()
+    mt = p.MAX_ALLOWED_TOTAL_FREQ
+    fixed = dict(group="G9", model="fixed", freq=fl, K=6, k=0, max_total=mt, precision=32, size_bits=32)
+    add_stream_case(col, "aec", fixed, alphabet, syms, 1000, lambda: ArithmeticEncoder(p, FixedFreqModel(fr, mt)),
+                    lambda: ArithmeticDecoder(p, FixedFreqModel(fr, mt)), tmp)
+    for init in (fl, [1] * 6):
+        fr_init = Frequencies(dict(zip(alphabet, init)))
+        add_stream_case(col, "aec", dict(fixed, model="iid", freq=init), alphabet, syms, 1000,
+                        lambda: ArithmeticEncoder(p, AdaptiveIIDFreqModel(fr_init, mt)),
+                        lambda: ArithmeticDecoder(p, AdaptiveIIDFreqModel(fr_init, mt)), tmp)
+    # halving rule reached in the second block (PRECISION = 16: cap 2^14)
+    p16 = AECParams(PRECISION=16)
+    fr4 = Frequencies(dict(zip("ABCD", [1] * 4)))
+    add_stream_case(col, "aec", dict(group="G9halve", model="iid", freq=[1] * 4, K=4, k=0, max_total=p16.MAX_ALLOWED_TOTAL_FREQ,
+                                     precision=16, size_bits=32), list("ABCD"), iid_indices([3, 1, 7, 2], 36000, seed=5),
+                    12000, lambda: ArithmeticEncoder(p16, AdaptiveIIDFreqModel(fr4, p16.MAX_ALLOWED_TOTAL_FREQ)),
+                    lambda: ArithmeticDecoder(p16, AdaptiveIIDFreqModel(fr4, p16.MAX_ALLOWED_TOTAL_FREQ)), tmp)
+    # order-k: counts AND the context (past_k) cross the block boundary
+    for K, k, n, bs in ((4, 1, 2500, 1000), (16, 1, 2500, 1000), (3, 2, 2500, 1000), (256, 1, 1200, 500), (3, 0, 700, 300)):
+        x = markov2_ref(n) if K == 3 else markov1(K, n)
+        alph = list(range(K))
+        add_stream_case(col, "aec", dict(group="G9", model="orderk", freq=[1] * K, K=K, k=k, max_total=mt, precision=32,
+                                         size_bits=32), alph, x, bs,
+                        lambda: ArithmeticEncoder(p, AdaptiveOrderKFreqModel(alph, k, mt)),
+                        lambda: ArithmeticDecoder(p, AdaptiveOrderKFreqModel(alph, k, mt)), tmp)
+
+    # G9file: encode_file / decode_file on a text file (TextFileDataStream, one character per symbol)
+    text = "".join(np.random.default_rng(11).choice(list("ab cd\ne"), size=1700, p=[.3, .2, .2, .1, .1, .05, .05]))
+    src, dst, back = (os.path.join(tmp, n) for n in ("in.txt", "out.bin", "back.txt"))
+    with open(src, "w") as f:
+        f.write(text)
+    chars = sorted(set(text))
+    for name in ("rans", "aec_iid", "aec_order1"):
+        if name == "rans":
+            frt = Frequencies({c: text.count(c) for c in chars})
+            params = rANSParams(frt)
+            enc, dec = rANSEncoder(params), rANSDecoder(params)
+            meta = dict(coder="rans", freq=[text.count(c) for c in chars], RF=params.RANGE_FACTOR, b=1, size_bits=32)
+        elif name == "aec_iid":
+            fri = Frequencies({c: 1 for c in chars})
+            enc = ArithmeticEncoder(p, AdaptiveIIDFreqModel(fri, mt))
+            dec = ArithmeticDecoder(p, AdaptiveIIDFreqModel(fri, mt))
+            meta = dict(coder="aec", model="iid", freq=[1] * len(chars), K=len(chars), k=0, max_total=mt, precision=32, size_bits=32)
+        else:
+            enc = ArithmeticEncoder(p, AdaptiveOrderKFreqModel(chars, 1, mt))
+            dec = ArithmeticDecoder(p, AdaptiveOrderKFreqModel(chars, 1, mt))
+            meta = dict(coder="aec", model="orderk", freq=[1] * len(chars), K=len(chars), k=1, max_total=mt, precision=32, size_bits=32)
+        enc.encode_file(src, dst, block_size=600)
+        dec.decode_file(dst, back)
+        assert open(back).read() == text
+        col.add(dict(meta, kind="file", group="G9file", block_size=600, alphabet="".join(chars)),
+                text=np.frombuffer(text.encode("ascii"), dtype=np.uint8), file=np.fromfile(dst, dtype=np.uint8))
+
+
 def main(out_dir):
-    for name, fn in (("rans", gen_rans), ("tans", gen_tans), ("range", gen_range), ("aec", gen_aec)):
+    for name, fn in (("rans", gen_rans), ("tans", gen_tans), ("range", gen_range), ("aec", gen_aec),
+                     ("stream", gen_stream)):
         col = Collector()
         fn(col, np.random.default_rng(12345))
         col.save(f"{out_dir}/golden_{name}.npz")

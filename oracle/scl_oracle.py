@@ -53,11 +53,14 @@ def lib():
         L.orc_range_decode.argtypes = [u8p, u64, u32p, u32, u32, u32, u8p, u64, u64p]
         L.orc_aec_encode.argtypes = [u8p, u64, C.c_int, u32, u32, u32p, u64, u32, u32, u8p, u64]
         L.orc_aec_decode.argtypes = [u8p, u64, C.c_int, u32, u32, u32p, u64, u32, u32, u8p, u64, u64p]
+        L.orc_aec_encode_st.argtypes = L.orc_aec_encode.argtypes + [u64p]
+        L.orc_aec_decode_st.argtypes = L.orc_aec_decode.argtypes + [u64p]
         L.orc_rans_encode_batch.argtypes = [u8p, u64, u64, u32p, u32, u64, u32, u32, u8p, u64, u64p]
         L.orc_rans_decode_batch.argtypes = [u8p, u64, u64, u64p, u32p, u32, u64, u32, u32, u8p, u64, u64p]
         for name in ("orc_rans_encode", "orc_rans_decode", "orc_tans_encode", "orc_tans_decode",
                      "orc_tans_tables", "orc_range_encode", "orc_range_decode", "orc_aec_encode",
-                     "orc_aec_decode", "orc_rans_encode_batch", "orc_rans_decode_batch"):
+                     "orc_aec_decode", "orc_aec_encode_st", "orc_aec_decode_st", "orc_rans_encode_batch",
+                     "orc_rans_decode_batch"):
             getattr(L, name).restype = i64
         _lib = L
     return _lib
@@ -153,24 +156,43 @@ def range_decode(packed, nbits, freq, precision=32, size_bits=32, cap=1 << 22):
 
 
 # ---- arithmetic coder ------------------------------------------------------------------------
-def aec_encode(sym, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32, size_bits=32):
+def aec_fresh_state(model_kind, K, k=0, f_init=None):
+    """State of a new coder object: [counts (K, or K^(k+1) for order-k, row-major)][flattened context index].
+    Pass it as ``state=`` to aec_encode / aec_decode; it is updated in place, which is how the reference carries
+    its freq_model from one encode_block / decode_block call to the next (quirk Q4)."""
+    if model_kind == MODEL_ORDERK:
+        counts = np.ones(K ** (k + 1), dtype=np.uint64)
+    else:
+        counts = np.asarray(f_init if f_init is not None else np.ones(K), dtype=np.uint64)
+    return np.concatenate([counts, np.zeros(1, np.uint64)])
+
+
+def _state_ptr(state):
+    if state is None:
+        return None
+    assert state.dtype == np.uint64 and state.flags.c_contiguous
+    return _p(state, C.c_uint64)
+
+
+def aec_encode(sym, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32, size_bits=32, state=None):
     sym = _u8(sym)
     f = _freq(f_init if f_init is not None else np.ones(K))
     out = _enc_out(sym.size, bits_per_sym=96, extra=256)
-    nb = _check(lib().orc_aec_encode(_p(sym, C.c_uint8), sym.size, model_kind, K, k, _p(f, C.c_uint32),
-                                     max_total, precision, size_bits, _p(out, C.c_uint8), out.size), "aec_encode")
+    nb = _check(lib().orc_aec_encode_st(_p(sym, C.c_uint8), sym.size, model_kind, K, k, _p(f, C.c_uint32),
+                                        max_total, precision, size_bits, _p(out, C.c_uint8), out.size,
+                                        _state_ptr(state)), "aec_encode")
     return out[: (nb + 7) // 8].copy(), nb
 
 
 def aec_decode(packed, nbits, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32,
-               size_bits=32, cap=1 << 22):
+               size_bits=32, cap=1 << 22, state=None):
     buf = _u8(packed)
     f = _freq(f_init if f_init is not None else np.ones(K))
     out = np.zeros(cap, dtype=np.uint8)
     n = C.c_uint64(0)
-    used = _check(lib().orc_aec_decode(_p(buf, C.c_uint8), nbits, model_kind, K, k, _p(f, C.c_uint32),
-                                       max_total, precision, size_bits, _p(out, C.c_uint8), cap,
-                                       C.byref(n)), "aec_decode")
+    used = _check(lib().orc_aec_decode_st(_p(buf, C.c_uint8), nbits, model_kind, K, k, _p(f, C.c_uint32),
+                                          max_total, precision, size_bits, _p(out, C.c_uint8), cap,
+                                          C.byref(n), _state_ptr(state)), "aec_decode")
     return out[: n.value].copy(), used
 
 

@@ -82,6 +82,15 @@ _SIGNATURES = {
     "scl_aec_decode_batch": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _vp]),
     "scl_aec_encode_host": (_int, _ENC_HOST),
     "scl_aec_decode_host": (_int, _DEC_HOST),
+    "scl_aec_state_bytes": (_u64, [_vp, _u64]),
+    "scl_aec_state_counts": (_u64, [_vp]),
+    "scl_aec_state_reset": (_int, [_vp, _vp, _u64, _u64, _vp]),
+    "scl_aec_state_upload": (_int, [_vp, _vp, _u64, _u64, _u32p, _u32p, _vp]),
+    "scl_aec_state_download": (_int, [_vp, _vp, _u64, _u64, _u32p, _u32p, _vp]),
+    "scl_aec_encode_batch_resume": (_int, _ENC_BATCH[:-1] + [_vp, _u64, _vp]),
+    "scl_aec_decode_batch_resume": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _vp]),
+    "scl_aec_encode_host_resume": (_int, _ENC_HOST + [_u32p, _u32p]),
+    "scl_aec_decode_host_resume": (_int, _DEC_HOST + [_u32p, _u32p]),
     "scl_streams_compact_scratch_bytes": (_u64, [_u64]),
     "scl_streams_compact": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp]),
     "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),

@@ -260,6 +260,90 @@ class AecModel(_DeviceModel):
         """True if chunks of up to max_symbols symbols run on the per-lane-LDS-table kernels (scl_aec_fast.hip)."""
         return bool(self._L.scl_aec_fast_path(self._h, int(max_symbols)))
 
+    # -- coder objects that live across blocks (reference quirk Q4; include/scl_hip.h "*_resume") -------------
+    def state_counts(self) -> int:
+        return int(self._L.scl_aec_state_counts(self._h))
+
+    def encode_host_resume(self, sym: np.ndarray, counts: np.ndarray, past_k: np.ndarray):
+        """one block of a coder whose model state is (counts, past_k); both arrays are updated in place"""
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        assert counts.dtype == np.uint32 and past_k.dtype == np.uint32 and counts.flags.c_contiguous
+        cap = self.slot_bytes(sym.size) + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        nbits = C.c_uint64(0)
+        rc = self._L.scl_aec_encode_host_resume(self._h, _lib.u8_ptr(sym), sym.size, _lib.u8_ptr(out), cap,
+                                                C.byref(nbits), _lib.u32_ptr(counts), _lib.u32_ptr(past_k))
+        _lib.check(rc, "scl_aec_encode_host_resume")
+        return out[: (nbits.value + 7) // 8], int(nbits.value)
+
+    def decode_host_resume(self, packed: np.ndarray, nbits: int, size_bits: int, counts: np.ndarray,
+                           past_k: np.ndarray):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        assert counts.dtype == np.uint32 and past_k.dtype == np.uint32 and counts.flags.c_contiguous
+        n = C.c_uint64(0)
+        rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
+        _lib.check(rc, "scl_stream_block_size_host")
+        out = np.zeros(max(int(n.value), 1), dtype=np.uint8)
+        n_out, used = C.c_uint64(0), C.c_uint64(0)
+        rc = self._L.scl_aec_decode_host_resume(self._h, _lib.u8_ptr(packed), int(nbits), _lib.u8_ptr(out),
+                                                int(n.value), C.byref(n_out), C.byref(used), _lib.u32_ptr(counts),
+                                                _lib.u32_ptr(past_k))
+        _lib.check(rc, "scl_aec_decode_host_resume")
+        return out[: n_out.value], int(used.value)
+
+    def alloc_state(self, n_coders: int, device):
+        """device state of n fresh coder objects (for encode_batch_resume / decode_batch_resume)"""
+        import torch
+
+        nbytes = int(self._L.scl_aec_state_bytes(self._h, int(n_coders)))
+        state = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            rc = self._L.scl_aec_state_reset(self._h, state.data_ptr(), state.numel(), int(n_coders),
+                                             torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(rc, "scl_aec_state_reset")
+        return state
+
+    def state_download(self, state, n_coders: int, coder: int):
+        import torch
+
+        counts = np.zeros(max(self.state_counts(), 1), np.uint32)
+        past = np.zeros(4, np.uint32)
+        rc = self._L.scl_aec_state_download(self._h, state.data_ptr(), int(n_coders), int(coder), _lib.u32_ptr(counts),
+                                            _lib.u32_ptr(past), torch.cuda.current_stream(state.device).cuda_stream)
+        _lib.check(rc, "scl_aec_state_download")
+        return counts[: self.state_counts()], past
+
+    def encode_batch_resume(self, sym, state, lens=None, out_stride: Optional[int] = None, stream=None,
+                            out: Optional[EncodedBatch] = None) -> EncodedBatch:
+        """chunk c CONTINUES coder c of ``state`` (from :meth:`alloc_state`) and leaves the advanced state there"""
+        import torch
+
+        assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
+        n_chunks, chunk_len = sym.shape
+        if out is None:
+            out = self.alloc_encoded(n_chunks, chunk_len, sym.device, out_stride)
+        st = stream if stream is not None else torch.cuda.current_stream(sym.device).cuda_stream
+        rc = self._L.scl_aec_encode_batch_resume(
+            self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None, chunk_len,
+            n_chunks, out.data.data_ptr(), out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
+            out.status.data_ptr(), state.data_ptr(), state.numel(), st)
+        _lib.check(rc, "scl_aec_encode_batch_resume")
+        return out
+
+    def decode_batch_resume(self, data, bit_offset, nbits, chunk_cap: int, state, stream=None, out=None):
+        import torch
+
+        n_chunks = int(bit_offset.numel())
+        dev = data.device
+        sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        rc = self._L.scl_aec_decode_batch_resume(
+            self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
+            sym.data_ptr(), sym.stride(0), int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr(),
+            state.data_ptr(), state.numel(), st)
+        _lib.check(rc, "scl_aec_decode_batch_resume")
+        return sym[:, :chunk_cap], lens, used, status
+
 
 def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     """Dense (or EncodedBlockWriter-framed) concatenation of a batch: -> (bytes tensor, int64 offsets[n+1])."""

@@ -3,11 +3,12 @@
 Drop-in for reference scl/compressors/arithmetic_coding.py: ``AECParams`` (:20-38), ``ArithmeticEncoder``
 (:41-161), ``ArithmeticDecoder`` (:164-287).  Kernels: ``csrc/scl_aec.hip``.
 
-Difference from the reference, stated once: an encoder / decoder object here starts every
-``encode_block`` / ``decode_block`` from a *fresh* copy of the model it was constructed with -- the unit
-the device batches is one chunk = one new coder.  The reference mutates ``freq_model`` across calls (it
-never overrides ``reset()``, quirk Q4), so a reference object used for several blocks is matched by one
-object per block here.  The first block of any object is bit-identical.
+Like the reference, an encoder / decoder object OWNS its ``freq_model`` and never resets it
+(arithmetic_coding.py:52-56,118; quirk Q4): every ``encode_block`` / ``decode_block`` starts from the state the
+model object is in -- counts and, for order-k, the last k symbols -- and leaves the advanced state in it, so
+block 2+ of ``encode()`` / ``encode_file()`` is bit-identical to the reference's as well
+(``scl_aec_{encode,decode}_host_resume``; fixture ``tests/golden/golden_stream.npz``).  The batched device API
+(``backend.models.AecModel.encode_batch``) keeps the other meaning: one chunk = one fresh coder.
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ from ..core.data_block import DataBlock
 from ..core.data_encoder_decoder import DataDecoder, DataEncoder
 from ..utils.bitarray_utils import BitArray
 from ._common import check_alphabet, indices_to_block, symbols_to_indices
-from .probability_models import FreqModelBase
+from .probability_models import KIND_FIXED, FreqModelBase
 
 __all__ = ["AECParams", "ArithmeticEncoder", "ArithmeticDecoder"]
 
@@ -53,6 +54,7 @@ class _AecBase:
                                    self.params.PRECISION, self.params.DATA_BLOCK_SIZE_BITS)
             self._alphabet = list(spec["alphabet"])
             self._index_of = {a: i for i, a in enumerate(self._alphabet)}
+            self._stateful = spec["kind"] != KIND_FIXED  # adaptive models: state is carried by the model object
         return self._model
 
 
@@ -68,7 +70,12 @@ class ArithmeticEncoder(_AecBase, DataEncoder):
         assert data_block.size < self.params.MAX_BLOCK_SIZE, \
             "choose a larger DATA_BLOCK_SIZE_BITS, as data_block.size is too big"
         try:
-            packed, nbits = model.encode_host(idx)
+            if self._stateful:
+                counts, past = self.freq_model.export_state()
+                packed, nbits = model.encode_host_resume(idx, counts, past)
+                self.freq_model.import_state(counts, past)
+            else:
+                packed, nbits = model.encode_host(idx)
         except SclHipError as e:
             if e.code == E_CHUNK and "TOTAL" in e.message:
                 raise AssertionError("the frequency total is too large (>= MAX_ALLOWED_TOTAL_FREQ)") from e
@@ -80,6 +87,12 @@ class ArithmeticDecoder(_AecBase, DataDecoder):
     def decode_block(self, encoded_bitarray: BitArray) -> Tuple[DataBlock, int]:
         """-> (DataBlock, num_bits_consumed); trailing bits are tolerated -- arithmetic_coding.py:203-287."""
         model = self._device_model()
-        idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
-                                      self.params.DATA_BLOCK_SIZE_BITS)
+        if self._stateful:
+            counts, past = self.freq_model.export_state()
+            idx, used = model.decode_host_resume(encoded_bitarray.packed(), len(encoded_bitarray),
+                                                 self.params.DATA_BLOCK_SIZE_BITS, counts, past)
+            self.freq_model.import_state(counts, past)
+        else:
+            idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
+                                          self.params.DATA_BLOCK_SIZE_BITS)
         return indices_to_block(idx, self._alphabet), used

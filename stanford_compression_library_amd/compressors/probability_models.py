@@ -1,10 +1,12 @@
 """Frequency models for the arithmetic coder (reference scl/compressors/probability_models.py:15-160).
 
-On the device each chunk owns a private copy of the model state (``csrc/scl_aec.hip``: ``LaneModel``);
-these classes are the host-side description of *which* model to instantiate per chunk, with the
-reference's constructor signatures.  They also keep a small host mirror (``freqs_current`` /
-``update_model``) so code that inspects a model between symbols keeps working; the coders never use the
-mirror to produce bits.
+Same constructor signatures, attributes (``freqs_current``, ``freqs_kplus1_tuple``, ``past_k``) and
+``update_model`` as the reference.  As in the reference the model OBJECT is the state of the coder that owns
+it: ``ArithmeticEncoder.encode_block`` / ``ArithmeticDecoder.decode_block`` read the object's current counts
+(and order-k context) before a block, run the block on the device from exactly that state, and write the
+advanced state back -- so a coder used for several blocks, or a model inspected between blocks, behaves like
+the reference's (which never resets ``freq_model``, arithmetic_coding.py:52-56,118).  The batched C-ABI entry
+points (``scl_aec_*_batch``) instead start every chunk from a fresh copy: ``device_spec`` describes that copy.
 """
 from __future__ import annotations
 
@@ -41,6 +43,16 @@ class FreqModelBase(abc.ABC):
     def device_spec(self) -> dict:
         return dict(kind=self._kind, K=len(self._alphabet), k=0, freq_init=self._initial_freq_list,
                     max_total=int(self.max_allowed_total_freq), alphabet=self._alphabet)
+
+    def export_state(self):
+        """(counts uint32 [K], past_k uint32 [0]) -- the canonical host form of include/scl_hip.h"""
+        return (np.asarray([int(f) for f in self.freqs_current.freq_list], dtype=np.uint32),
+                np.zeros(1, dtype=np.uint32))
+
+    def import_state(self, counts, past_k):
+        fd = self.freqs_current.freq_dict
+        for sym, f in zip(list(fd.keys()), counts.tolist()):
+            fd[sym] = int(f)
 
 
 class FixedFreqModel(FreqModelBase):
@@ -97,3 +109,13 @@ class AdaptiveOrderKFreqModel(FreqModelBase):
     def device_spec(self) -> dict:
         return dict(kind=self._kind, K=len(self._alphabet), k=int(self.k), freq_init=None,
                     max_total=int(self.max_allowed_total_freq), alphabet=self._alphabet)
+
+    def export_state(self):
+        past = np.zeros(max(self.k, 1), dtype=np.uint32)
+        past[: self.k] = self.past_k
+        return np.ascontiguousarray(self.freqs_kplus1_tuple, dtype=np.uint32).ravel(), past
+
+    def import_state(self, counts, past_k):
+        self.freqs_kplus1_tuple[...] = counts.astype(self.freqs_kplus1_tuple.dtype).reshape(
+            self.freqs_kplus1_tuple.shape)
+        self.past_k = [int(v) for v in past_k[: self.k]]

@@ -30,6 +30,8 @@
 //            decoder's search two dependent 64-byte reads, instead of a scan of the whole row.
 #include <string.h>
 
+#include <vector>
+
 #include "scl_aec_internal.h"
 
 // Per-lane frequency model (one of the three kinds); the coders only see counts through rd()/wr().
@@ -56,12 +58,17 @@ struct LaneModel {
         else
             cnt[cell] = v - ((P->kind == SCL_MODEL_ORDERK) ? 1u : 0u);
     }
-    __device__ __forceinline__ void init(const AecDev *P_, u32 *scratch, u64 chunk, u16 *lds_col) {
+    // ctx_state != nullptr: coder `chunk` CONTINUES from the counts already in its scratch region and from
+    // ctx_state[chunk] (the reference's freq_model object lives across encode_block calls, quirk Q4); the
+    // kernels store the context back when the block is done.  Only with LDS16 = false.
+    __device__ __forceinline__ void init(const AecDev *P_, u32 *scratch, u64 chunk, u16 *lds_col,
+                                         const u64 *ctx_state = nullptr) {
         P = P_;
-        ctx = 0;
+        ctx = ctx_state ? ctx_state[chunk] : 0;
         bad = 0;
         lcnt = lds_col;
         cnt = (!LDS16 && scratch) ? scratch + chunk * P_->cells : nullptr;
+        if (!LDS16 && ctx_state) return;
         if (LDS16) {
             for (u64 j = 0; j < P->cells; ++j) lcnt[j * 256] = (u16)((P->kind == SCL_MODEL_IID) ? P->d_freq[j] : 1u);
         } else if (P->kind == SCL_MODEL_IID) {
@@ -227,7 +234,8 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
                                                         const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                         u8 *__restrict__ out, u64 out_stride,
                                                         u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
-                                                        u32 *__restrict__ status, u32 *__restrict__ scratch) {
+                                                        u32 *__restrict__ status, u32 *__restrict__ scratch,
+                                                        u64 *__restrict__ ctx_state) {
     __shared__ u32 s_f[256];
     __shared__ u32 s_c[256];
     __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     const u8 *src = sym + c * sym_stride;
     const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
     LaneModel<LDS16> mdl;
-    mdl.init(&P, scratch, c, s_cnt + threadIdx.x);
+    mdl.init(&P, scratch, c, s_cnt + threadIdx.x, ctx_state);
     FwdBitWriter w;
     w.init(out + c * out_stride, out_stride);
     u32 st = 0;
@@ -294,6 +302,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
         w.put_run(0, pending);
     }
     if (mdl.bad) st |= SCL_ST_TOTAL;
+    if (ctx_state) ctx_state[c] = mdl.ctx;
     const u64 total = w.finish();
     if (w.overflow) st |= SCL_ST_CAPACITY;
     out_bit_off[c] = c * out_stride * 8;
@@ -307,7 +316,8 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
                                                         const u32 *__restrict__ in_nbits, u64 n_chunks,
                                                         u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
                                                         u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
-                                                        u32 *__restrict__ status, u32 *__restrict__ scratch) {
+                                                        u32 *__restrict__ status, u32 *__restrict__ scratch,
+                                                        u64 *__restrict__ ctx_state) {
     __shared__ u32 s_f[256];
     __shared__ u32 s_c[256];
     __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
@@ -338,7 +348,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
         return;
     }
     LaneModel<LDS16> mdl;
-    mdl.init(&P, scratch, c, s_cnt + threadIdx.x);
+    mdl.init(&P, scratch, c, s_cnt + threadIdx.x, ctx_state);
     u8 *dst = out_sym + c * out_stride;
     // bit positions relative to the first bit after the header; bits past the end read as 0 (:258-261)
     const u64 body = r.pos;
@@ -390,6 +400,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
     }
     if (e == P.P) e = P.P - 1;  // Python's loop variable after an unbroken range(PRECISION)
     if (mdl.bad) st |= SCL_ST_TOTAL;
+    if (ctx_state) ctx_state[c] = mdl.ctx;
     consumed[c] = (u32)((i64)(used + P.size_bits) - ((i64)e - 1));
     if (status) status[c] = st;
 }
@@ -573,11 +584,11 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     if (aec_use_lds(m, chunk_len))
         hipLaunchKernelGGL(aec_encode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
-                           (u32 *)d_scratch);
+                           (u32 *)d_scratch, (u64 *)nullptr);
     else
         hipLaunchKernelGGL(aec_encode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
-                           (u32 *)d_scratch);
+                           (u32 *)d_scratch, (u64 *)nullptr);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -622,11 +633,190 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     if (aec_use_lds(m, out_cap))
         hipLaunchKernelGGL(aec_decode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status, (u32 *)d_scratch);
+                           d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
     else
         hipLaunchKernelGGL(aec_decode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
-                           d_consumed, d_status, (u32 *)d_scratch);
+                           d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+// ---- coder state carried across blocks (quirk Q4) -----------------------------------------------------------
+// The reference's ArithmeticEncoder / ArithmeticDecoder own a freq_model object and never reset it
+// (arithmetic_coding.py:52-56,118): block i+1 of DataEncoder.encode (core/data_encoder_decoder.py:57-69) is coded
+// with the counts AND the order-k context block i left behind.  Device state of n coders:
+//   [cells * n u32: the same private model regions the batch kernels use as scratch][pad to 256 B][u64 ctx[n]]
+// scl_aec_*_batch_resume run the any-parameter kernels on it without re-initialising anything.
+static u64 aec_state_cells_bytes(const scl_aec_model *m, u64 n_coders) {
+    return scl_round_up(m->dev.cells * n_coders * sizeof(u32), 256);
+}
+
+extern "C" uint64_t scl_aec_state_bytes(const scl_aec_model *m, uint64_t n_coders) {
+    if (!m) return 0;
+    return aec_state_cells_bytes(m, n_coders) + scl_round_up(n_coders * sizeof(u64), 256);
+}
+
+extern "C" uint64_t scl_aec_state_counts(const scl_aec_model *m) {
+    if (!m || m->dev.kind == SCL_MODEL_FIXED) return 0;
+    return (m->dev.kind == SCL_MODEL_ORDERK) ? m->dev.ctx_mod * m->dev.K : m->dev.K;
+}
+
+__global__ void aec_state_fill_iid(u32 *__restrict__ cnt, const u32 *__restrict__ freq, u32 K, u64 total) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) cnt[i] = freq[i % K];
+}
+
+extern "C" int scl_aec_state_reset(const scl_aec_model *m, void *d_state, uint64_t state_bytes, uint64_t n_coders,
+                                   void *stream) {
+    SCL_REQUIRE(m && d_state, "aec_state_reset: null pointer argument");
+    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_coders), "aec_state_reset: state of %llu bytes required",
+                (unsigned long long)scl_aec_state_bytes(m, n_coders));
+    hipStream_t st = (hipStream_t)stream;
+    SCL_HIP_TRY(hipMemsetAsync(d_state, 0, scl_aec_state_bytes(m, n_coders), st));  // ORDERK: count - 1 = 0; ctx = 0
+    if (m->dev.kind == SCL_MODEL_IID && n_coders) {
+        const u64 total = (u64)m->dev.K * n_coders;
+        hipLaunchKernelGGL(aec_state_fill_iid, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, (u32 *)d_state,
+                           m->dev.d_freq, m->dev.K, total);
+        SCL_HIP_TRY(hipGetLastError());
+    }
+    return SCL_OK;
+}
+
+// canonical host form <-> device form of ONE coder's state.  h_counts: scl_aec_state_counts() actual counts
+// (IID: [K]; ORDERK: [K^(k+1)] row-major, last axis = next symbol, = freqs_kplus1_tuple.ravel()); h_past_k: the
+// last k symbol indices, oldest first (= past_k, probability_models.py:116).
+static int aec_state_to_device(const scl_aec_model *m, const u32 *h_counts, const u32 *h_past_k, std::vector<u32> &cells,
+                               u64 &ctx) {
+    const AecDev &P = m->dev;
+    cells.assign(P.cells, 0);
+    ctx = 0;
+    if (P.kind == SCL_MODEL_FIXED) return SCL_OK;
+    const u64 n = scl_aec_state_counts(m);
+    for (u64 i = 0; i < n; ++i) SCL_REQUIRE(h_counts[i] >= 1, "aec_state: count %llu is zero", (unsigned long long)i);
+    if (P.kind == SCL_MODEL_IID) {
+        for (u32 j = 0; j < P.K; ++j) cells[j] = h_counts[j];
+        return SCL_OK;
+    }
+    for (u32 i = 0; i < P.k; ++i) {
+        SCL_REQUIRE(h_past_k[i] < P.K, "aec_state: past symbol index %u outside the alphabet", h_past_k[i]);
+        ctx = ctx * P.K + h_past_k[i];
+    }
+    for (u64 row = 0; row < P.ctx_mod; ++row)
+        for (u32 s = 0; s < P.K; ++s) {
+            const u32 extra = h_counts[row * P.K + s] - 1;
+            if (P.fenwick) {
+                cells[row * P.row_cells + 16 + s] = extra;
+                cells[row * P.row_cells + (s >> 4)] += extra;
+            } else {
+                cells[row * P.K + s] = extra;
+            }
+        }
+    return SCL_OK;
+}
+
+static void aec_state_from_device(const scl_aec_model *m, const std::vector<u32> &cells, u64 ctx, u32 *h_counts,
+                                  u32 *h_past_k) {
+    const AecDev &P = m->dev;
+    if (P.kind == SCL_MODEL_FIXED) return;
+    if (P.kind == SCL_MODEL_IID) {
+        for (u32 j = 0; j < P.K; ++j) h_counts[j] = cells[j];
+        return;
+    }
+    for (u64 row = 0; row < P.ctx_mod; ++row)
+        for (u32 s = 0; s < P.K; ++s)
+            h_counts[row * P.K + s] = 1 + (P.fenwick ? cells[row * P.row_cells + 16 + s] : cells[row * P.K + s]);
+    for (u32 i = P.k; i-- > 0;) {
+        h_past_k[i] = (u32)(ctx % P.K);
+        ctx /= P.K;
+    }
+}
+
+extern "C" int scl_aec_state_upload(const scl_aec_model *m, void *d_state, uint64_t n_coders, uint64_t coder,
+                                    const uint32_t *h_counts, const uint32_t *h_past_k, void *stream) {
+    SCL_REQUIRE(m && d_state && coder < n_coders, "aec_state_upload: bad arguments");
+    SCL_REQUIRE(m->dev.kind == SCL_MODEL_FIXED || (h_counts && (m->dev.k == 0 || h_past_k)),
+                "aec_state_upload: null state arrays");
+    std::vector<u32> cells;
+    u64 ctx;
+    int rc = aec_state_to_device(m, h_counts, h_past_k, cells, ctx);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    u8 *base = (u8 *)d_state;
+    if (!cells.empty())
+        SCL_HIP_TRY(hipMemcpyAsync(base + coder * m->dev.cells * sizeof(u32), cells.data(), cells.size() * sizeof(u32),
+                                   hipMemcpyHostToDevice, st));
+    SCL_HIP_TRY(hipMemcpyAsync(base + aec_state_cells_bytes(m, n_coders) + coder * sizeof(u64), &ctx, sizeof(u64),
+                               hipMemcpyHostToDevice, st));
+    SCL_HIP_TRY(hipStreamSynchronize(st));  // the staging vector dies with this call
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_state_download(const scl_aec_model *m, const void *d_state, uint64_t n_coders, uint64_t coder,
+                                      uint32_t *h_counts, uint32_t *h_past_k, void *stream) {
+    SCL_REQUIRE(m && d_state && coder < n_coders, "aec_state_download: bad arguments");
+    SCL_REQUIRE(m->dev.kind == SCL_MODEL_FIXED || (h_counts && (m->dev.k == 0 || h_past_k)),
+                "aec_state_download: null state arrays");
+    std::vector<u32> cells(m->dev.cells);
+    u64 ctx = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const u8 *base = (const u8 *)d_state;
+    if (!cells.empty())
+        SCL_HIP_TRY(hipMemcpyAsync(cells.data(), base + coder * m->dev.cells * sizeof(u32), cells.size() * sizeof(u32),
+                                   hipMemcpyDeviceToHost, st));
+    SCL_HIP_TRY(hipMemcpyAsync(&ctx, base + aec_state_cells_bytes(m, n_coders) + coder * sizeof(u64), sizeof(u64),
+                               hipMemcpyDeviceToHost, st));
+    SCL_HIP_TRY(hipStreamSynchronize(st));
+    aec_state_from_device(m, cells, ctx, h_counts, h_past_k);
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                           const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                           uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                           uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
+                                           uint64_t state_bytes, void *stream) {
+    SCL_REQUIRE(m, "aec_encode_batch_resume: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED)  // nothing to carry
+        return scl_aec_encode_batch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                    d_out_bit_offset, d_out_nbits, d_status, nullptr, 0, stream);
+    SCL_REQUIRE(d_sym && d_out && d_out_bit_offset && d_out_nbits && d_state,
+                "aec_encode_batch_resume: null pointer argument");
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
+                "aec_encode_batch_resume: bad out_stride %llu", (unsigned long long)out_stride);
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_state & 255) == 0,
+                "aec_encode_batch_resume: d_out must be 16-byte, d_state 256-byte aligned");
+    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_chunks), "aec_encode_batch_resume: state of %llu bytes required",
+                (unsigned long long)scl_aec_state_bytes(m, n_chunks));
+    if (n_chunks == 0) return SCL_OK;
+    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_chunks));
+    hipLaunchKernelGGL(aec_encode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       m->dev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                       d_out_nbits, d_status, (u32 *)d_state, ctx_state);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                           const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
+                                           uint8_t *d_out_sym, uint64_t out_stride, uint32_t out_cap,
+                                           uint32_t *d_out_lens, uint32_t *d_consumed, uint32_t *d_status,
+                                           void *d_state, uint64_t state_bytes, void *stream) {
+    SCL_REQUIRE(m, "aec_decode_batch_resume: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED)
+        return scl_aec_decode_batch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+                                    out_cap, d_out_lens, d_consumed, d_status, nullptr, 0, stream);
+    SCL_REQUIRE(d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed && d_state,
+                "aec_decode_batch_resume: null pointer argument");
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0 && ((uintptr_t)d_state & 255) == 0,
+                "aec_decode_batch_resume: d_in must be 4-byte, d_state 256-byte aligned");
+    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_chunks), "aec_decode_batch_resume: state of %llu bytes required",
+                (unsigned long long)scl_aec_state_bytes(m, n_chunks));
+    if (n_chunks == 0) return SCL_OK;
+    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_chunks));
+    hipLaunchKernelGGL(aec_decode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       m->dev, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                       d_out_lens, d_consumed, d_status, (u32 *)d_state, ctx_state);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -656,5 +846,54 @@ extern "C" int scl_aec_encode_host(const scl_aec_model *m, const uint8_t *h_sym,
 extern "C" int scl_aec_decode_host(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits, uint8_t *h_out_sym,
                                    uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
     HostDecodeCall call = {aec_run_dec, aec_scratch};
+    return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}
+
+// one block of a coder whose model state lives on the host between calls (what the drop-in classes do with the
+// caller's freq_model object): upload -> code one block -> download
+struct AecHostState {
+    uint32_t *counts, *past_k;
+};
+static u64 aec_state1(const void *model) { return scl_aec_state_bytes((const scl_aec_model *)model, 1); }
+static int aec_state_pre(const void *model, void *d_scratch, void *user) {
+    const AecHostState *hs = (const AecHostState *)user;
+    return scl_aec_state_upload((const scl_aec_model *)model, d_scratch, 1, 0, hs->counts, hs->past_k, nullptr);
+}
+static int aec_state_post(const void *model, const void *d_scratch, void *user) {
+    const AecHostState *hs = (const AecHostState *)user;
+    return scl_aec_state_download((const scl_aec_model *)model, d_scratch, 1, 0, hs->counts, hs->past_k, nullptr);
+}
+static int aec_run_enc_resume(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                              u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_encode_batch_resume((const scl_aec_model *)model, d_sym, n, nullptr, n, 1, d_out, out_stride,
+                                       d_bit_off, d_nbits, d_status, d_scratch, scratch_bytes, nullptr);
+}
+static int aec_run_dec_resume(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off,
+                              const u32 *d_in_nbits, u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed,
+                              u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_decode_batch_resume((const scl_aec_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
+                                       d_out_sym, scl_round_up((u64)out_cap + 1, 16), out_cap, d_out_len, d_consumed,
+                                       d_status, d_scratch, scratch_bytes, nullptr);
+}
+
+extern "C" int scl_aec_encode_host_resume(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,
+                                          uint64_t out_cap_bytes, uint64_t *nbits, uint32_t *h_counts,
+                                          uint32_t *h_past_k) {
+    SCL_REQUIRE(m, "aec_encode_host_resume: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED) return scl_aec_encode_host(m, h_sym, n, h_out, out_cap_bytes, nbits);
+    SCL_REQUIRE(h_counts && (m->dev.k == 0 || h_past_k), "aec_encode_host_resume: null state arrays");
+    AecHostState hs = {h_counts, h_past_k};
+    HostEncodeCall call = {aec_run_enc_resume, aec_slot, aec_state1, aec_state_pre, aec_state_post, &hs};
+    return scl_host_encode_one(call, m, h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_aec_decode_host_resume(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                          uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed,
+                                          uint32_t *h_counts, uint32_t *h_past_k) {
+    SCL_REQUIRE(m, "aec_decode_host_resume: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED) return scl_aec_decode_host(m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+    SCL_REQUIRE(h_counts && (m->dev.k == 0 || h_past_k), "aec_decode_host_resume: null state arrays");
+    AecHostState hs = {h_counts, h_past_k};
+    HostDecodeCall call = {aec_run_dec_resume, aec_state1, aec_state_pre, aec_state_post, &hs};
     return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
 }

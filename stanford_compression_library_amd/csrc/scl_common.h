@@ -15,7 +15,7 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 #define SCL_WAVE 64
-#define SCL_ABI_VERSION 1
+#define SCL_ABI_VERSION 2
 
 // ---- host-side error plumbing ------------------------------------------------------------------
 void scl_set_error(const char *fmt, ...);
@@ -74,12 +74,20 @@ struct HostEncodeCall {
                u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes);
     u64 (*slot_bytes)(const void *model, u64 n);
     u64 (*scratch_bytes)(const void *model);
+    // optional hooks around the launch (coder state carried across blocks): pre() fills d_scratch before the
+    // launch, post() reads it back after the device has finished; `user` is handed to both
+    int (*pre)(const void *model, void *d_scratch, void *user) = nullptr;
+    int (*post)(const void *model, const void *d_scratch, void *user) = nullptr;
+    void *user = nullptr;
 };
 struct HostDecodeCall {
     int (*run)(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
                u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *d_scratch,
                u64 scratch_bytes);
     u64 (*scratch_bytes)(const void *model);
+    int (*pre)(const void *model, void *d_scratch, void *user) = nullptr;
+    int (*post)(const void *model, const void *d_scratch, void *user) = nullptr;
+    void *user = nullptr;
 };
 int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 *h_sym, u64 n, u8 *h_out,
                         u64 out_cap_bytes, u64 *nbits);

@@ -322,6 +322,7 @@ int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 
     u32 *d_status = d_nbits + 1;
     if (n) SCL_HIP_TRY(hipMemcpy(d_sym.p, h_sym, n, hipMemcpyHostToDevice));
     SCL_HIP_TRY(hipMemset(d_meta.p, 0, 64));
+    if (call.pre && (rc = call.pre(model, d_scr.p, call.user))) return rc;
     rc = call.run(model, (const u8 *)d_sym.p, (u32)n, (u8 *)d_slot.p, slot, d_bit_off, d_nbits, d_status, d_scr.p,
                   scratch_bytes);
     if (rc) return rc;
@@ -340,6 +341,7 @@ int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 
     }
     SCL_HIP_TRY(hipMemcpy(h_out, d_dense.p, bytes, hipMemcpyDeviceToHost));
     *nbits = meta[0];
+    if (call.post && (rc = call.post(model, d_scr.p, call.user))) return rc;
     return SCL_OK;
 }
 
@@ -364,6 +366,7 @@ int scl_host_decode_one(const HostDecodeCall &call, const void *model, const u8 
     SCL_HIP_TRY(hipMemset(d_meta.p, 0, 64));
     SCL_HIP_TRY(hipMemcpy(d_bit_off, &h_bit_off, 8, hipMemcpyHostToDevice));
     SCL_HIP_TRY(hipMemcpy(d_nb, &h_nb, 4, hipMemcpyHostToDevice));
+    if (call.pre && (rc = call.pre(model, d_scr.p, call.user))) return rc;
     rc = call.run(model, (const u8 *)d_in.p, in_bytes + 32, d_bit_off, d_nb, (u8 *)d_out.p, (u32)out_cap, d_len, d_used,
                   d_status, d_scr.p, scratch_bytes);
     if (rc) return rc;
@@ -374,5 +377,6 @@ int scl_host_decode_one(const HostDecodeCall &call, const void *model, const u8 
     *consumed = meta[1];
     if ((rc = status_to_error(meta[2], "decode_host"))) return rc;
     if (meta[0]) SCL_HIP_TRY(hipMemcpy(h_out_sym, d_out.p, meta[0], hipMemcpyDeviceToHost));
+    if (call.post && (rc = call.post(model, d_scr.p, call.user))) return rc;
     return SCL_OK;
 }

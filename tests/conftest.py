@@ -71,3 +71,28 @@ def load_golden(name):
 
 def golden_ids(cases):
     return [repr(c) for c in cases]
+
+
+def stream_blocks(case):
+    """[(symbol indices, packed bits, nbits)] of one golden_stream case, block by block"""
+    sym, nbits, packed = case.arr("sym"), case.arr("block_nbits"), case.arr("block_out")
+    out, pos = [], 0
+    for i, nb in enumerate(nbits.tolist()):
+        nbytes = (nb + 7) // 8
+        out.append((sym[i * case.block_size:(i + 1) * case.block_size], packed[pos:pos + nbytes], nb))
+        pos += nbytes
+    return out
+
+
+def frame_blocks(blocks):
+    """EncodedBlockWriter framing of [(packed bits, nbits)] restated on bytes (encoded_stream.py:23-46,94-103):
+    [u32 BE payload bytes][3-bit pad count][pad zeros][bits]"""
+    out = []
+    for packed, nb in blocks:
+        pad = (-(nb + 3)) % 8
+        bits = np.concatenate([np.unpackbits(np.array([pad << 5], np.uint8))[:3], np.zeros(pad, np.uint8),
+                               np.unpackbits(np.asarray(packed, np.uint8))[:nb]])
+        payload = np.packbits(bits)
+        out.append(np.frombuffer(len(payload).to_bytes(4, "big"), np.uint8))
+        out.append(payload)
+    return np.concatenate(out) if out else np.zeros(0, np.uint8)

@@ -81,3 +81,52 @@ def test_aec(case):
         sym, got_used = orc.aec_decode(packed, total, **kw)
         assert got_used == used
         assert np.array_equal(sym, case.arr("sym"))
+
+
+# ---- G9: multi-block streams written by ONE reference coder object through DataEncoder.encode --------------
+STREAM = [c for c in load_golden("stream") if c.kind in ("rans", "tans", "range", "aec")]
+
+
+@pytest.mark.parametrize("case", STREAM, ids=golden_ids(STREAM))
+def test_stream_blocks(case):
+    """every block of the reference's stream, the framed file, and -- for the arithmetic coder -- the model
+    state the reference object is left in: the adaptive models are carried from block to block (quirk Q4)"""
+    from conftest import frame_blocks, stream_blocks
+
+    blocks = stream_blocks(case)
+    assert len(blocks) == 3
+    if case.kind == "aec":
+        kw = dict(model_kind=MODEL[case.model], K=case.K, k=case.k, f_init=case.freq, max_total=case.max_total,
+                  precision=case.precision, size_bits=case.size_bits)
+        st_e = orc.aec_fresh_state(MODEL[case.model], case.K, case.k, case.freq)
+        st_d = st_e.copy()
+        enc = lambda s: orc.aec_encode(s, state=st_e, **kw)
+        dec = lambda p, nb: orc.aec_decode(p, nb, state=st_d, **kw)
+    elif case.kind == "rans":
+        enc = lambda s: orc.rans_encode(s, case.freq, RF=case.RF, b=case.b, size_bits=case.size_bits)
+        dec = lambda p, nb: orc.rans_decode(p, nb, case.freq, RF=case.RF, b=case.b, size_bits=case.size_bits)
+    elif case.kind == "tans":
+        enc = lambda s: orc.tans_encode(s, case.freq, RF=case.RF, size_bits=case.size_bits)
+        dec = lambda p, nb: orc.tans_decode(p, nb, case.freq, RF=case.RF, size_bits=case.size_bits)
+    else:
+        enc = lambda s: orc.range_encode(s, case.freq, precision=case.precision, size_bits=case.size_bits)
+        dec = lambda p, nb: orc.range_decode(p, nb, case.freq, precision=case.precision, size_bits=case.size_bits)
+    got = []
+    for sym, packed, nb in blocks:
+        out, got_nb = enc(sym)
+        assert got_nb == nb and np.array_equal(out, packed)
+        got.append((out, got_nb))
+        back, used = dec(packed, nb)
+        assert used == nb and np.array_equal(back, sym)
+    assert np.array_equal(frame_blocks(got), case.arr("file"))
+    if case.kind == "aec" and case.model != "fixed":
+        for st, tag in ((st_e, "enc"), (st_d, "dec")):
+            assert np.array_equal(st[:-1].astype(np.int64), case.arr(f"{tag}_counts"))
+            ctx = 0
+            for s in case.arr(f"{tag}_past_k").tolist():
+                ctx = ctx * case.K + s
+            assert int(st[-1]) == ctx
+    if case.kind == "aec" and case.model != "fixed":
+        # a fresh model per block (the batch semantics) must differ from the carried one after block 0
+        out, nb = orc.aec_encode(blocks[1][0], **kw)
+        assert nb != blocks[1][2] or not np.array_equal(out, blocks[1][1])
