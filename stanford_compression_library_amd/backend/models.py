@@ -101,6 +101,19 @@ class _DeviceModel:
             return None, 0
         return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
+    def _keep_scratch(self, stream_handle, scratch):
+        """the kernels read the scratch asynchronously: keep the tensor referenced until the next call on the SAME
+        stream replaces it (stream order then guarantees the previous launch is done with the old one)"""
+        if not hasattr(self, "_scratch_by_stream"):
+            self._scratch_by_stream = {}
+        self._scratch_by_stream[int(stream_handle or 0)] = scratch
+        if scratch is not None and stream_handle:
+            import torch
+
+            if int(stream_handle) != torch.cuda.current_stream(scratch.device).cuda_stream:
+                # allocated on torch's current stream, used on another: tell the caching allocator
+                scratch.record_stream(torch.cuda.ExternalStream(int(stream_handle), device=scratch.device))
+
     def alloc_encoded(self, n_chunks: int, chunk_len: int, device, out_stride: Optional[int] = None) -> EncodedBatch:
         """Output buffers of a batched encode (reusable across calls of the same shape)."""
         import torch
@@ -142,8 +155,9 @@ class _DeviceModel:
         if self._needs_scratch:
             scratch, nbytes = self._scratch(n_chunks, dev)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
-            self._last_scratch = scratch  # keep alive until the stream is done
-        rc = self._fn("encode_batch")(*args, st)
+            self._keep_scratch(st, scratch)
+        with torch.cuda.device(dev):  # the library launches on the CURRENT device and checks it is the model's
+            rc = self._fn("encode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
         return out
 
@@ -176,8 +190,9 @@ class _DeviceModel:
         if self._needs_scratch:
             scratch, nbytes = self._scratch(n_chunks, dev)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
-            self._last_scratch = scratch
-        rc = self._fn("decode_batch")(*args, st)
+            self._keep_scratch(st, scratch)
+        with torch.cuda.device(dev):
+            rc = self._fn("decode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_decode_batch")
         return sym[:, :chunk_cap], lens, used, status
 
@@ -323,10 +338,11 @@ class AecModel(_DeviceModel):
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, sym.device, out_stride)
         st = stream if stream is not None else torch.cuda.current_stream(sym.device).cuda_stream
-        rc = self._L.scl_aec_encode_batch_resume(
-            self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None, chunk_len,
-            n_chunks, out.data.data_ptr(), out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
-            out.status.data_ptr(), state.data_ptr(), state.numel(), st)
+        with torch.cuda.device(sym.device):
+            rc = self._L.scl_aec_encode_batch_resume(
+                self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None, chunk_len,
+                n_chunks, out.data.data_ptr(), out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
+                out.status.data_ptr(), state.data_ptr(), state.numel(), st)
         _lib.check(rc, "scl_aec_encode_batch_resume")
         return out
 
@@ -337,10 +353,11 @@ class AecModel(_DeviceModel):
         dev = data.device
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        rc = self._L.scl_aec_decode_batch_resume(
-            self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
-            sym.data_ptr(), sym.stride(0), int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr(),
-            state.data_ptr(), state.numel(), st)
+        with torch.cuda.device(dev):
+            rc = self._L.scl_aec_decode_batch_resume(
+                self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
+                sym.data_ptr(), sym.stride(0), int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr(),
+                state.data_ptr(), state.numel(), st)
         _lib.check(rc, "scl_aec_decode_batch_resume")
         return sym[:, :chunk_cap], lens, used, status
 
@@ -352,16 +369,22 @@ def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     L = _lib.load()
     dev = enc.data.device
     n = enc.n_chunks
+    tstream = stream if isinstance(stream, torch.cuda.Stream) else None
+    if stream is not None and tstream is None:
+        tstream = torch.cuda.ExternalStream(int(stream), device=dev)  # a raw hipStream_t
+    if tstream is None:
+        tstream = torch.cuda.current_stream(dev)
     # capacity: every record is at most ceil(nbits/8) (+5 framed) bytes
-    total_bits = int(enc.nbits.to(torch.int64).sum().item())
+    with torch.cuda.stream(tstream):  # nbits were written on that stream
+        total_bits = int(enc.nbits.to(torch.int64).sum().item())
     cap = total_bits // 8 + n * (6 if framed else 1) + 16
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.scl_streams_compact_scratch_bytes(n)), dtype=torch.uint8, device=dev)
-    st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-    rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), n,
-                               _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), cap,
-                               offsets.data_ptr(), scratch.data_ptr(), st)
+    with torch.cuda.device(dev):
+        rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), n,
+                                   _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), cap,
+                                   offsets.data_ptr(), scratch.data_ptr(), tstream.cuda_stream)
     _lib.check(rc, "scl_streams_compact")
-    torch.cuda.current_stream(dev).synchronize()
+    tstream.synchronize()  # the stream the kernels were queued on: results readable, scratch reusable on return
     return out, offsets

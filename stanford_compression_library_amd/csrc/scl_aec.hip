@@ -417,6 +417,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "aec_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32", size_bits);
     SCL_REQUIRE(max_total >= 2, "aec_model_create: max_allowed_total_freq too small");
     scl_aec_model *m = new scl_aec_model();
+    m->device = scl_current_device();
     m->dev.kind = model_kind;
     m->dev.K = K;
     m->dev.k = 0;
@@ -545,6 +546,7 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
                                     uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
                                     uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes, void *stream) {
     SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "aec_encode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "aec_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
                 "aec_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "aec_encode_batch: d_out must be 16-byte aligned");
@@ -600,6 +602,7 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
                                     void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "aec_decode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "aec_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -777,6 +780,7 @@ extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t
                                            uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
                                            uint64_t state_bytes, void *stream) {
     SCL_REQUIRE(m, "aec_encode_batch_resume: null model");
+    if (int rc_dev = scl_check_device(m->device, "aec_encode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)  // nothing to carry
         return scl_aec_encode_batch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                     d_out_bit_offset, d_out_nbits, d_status, nullptr, 0, stream);
@@ -803,6 +807,7 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
                                            uint32_t *d_out_lens, uint32_t *d_consumed, uint32_t *d_status,
                                            void *d_state, uint64_t state_bytes, void *stream) {
     SCL_REQUIRE(m, "aec_decode_batch_resume: null model");
+    if (int rc_dev = scl_check_device(m->device, "aec_decode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)
         return scl_aec_decode_batch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                     out_cap, d_out_lens, d_consumed, d_status, nullptr, 0, stream);

@@ -18,6 +18,7 @@ struct AecDev {
 };
 
 struct scl_aec_model {
+    int device;  // hipGetDevice() at create: the tables live there (scl_check_device)
     AecDev dev;
     u32 *d_freq, *d_cum;
     u32 h_freq[256];  // host copy of the initial frequencies (all ones for ORDERK)

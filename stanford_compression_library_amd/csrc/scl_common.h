@@ -50,6 +50,12 @@ static inline u32 scl_bit_width_u64(u64 x) {  // get_bit_width, bitarray_utils.p
 
 static inline u64 scl_round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
+// One model handle = one device: its tables live in the HBM of the device that was current at *_model_create.
+// The batch entry points launch on the CURRENT device, so they refuse a handle made on another one (SCL_E_PARAM)
+// instead of dereferencing a foreign device's pointers.  (scl_core.hip)
+int scl_current_device(void);
+int scl_check_device(int model_device, const char *what);
+
 // RAII-less scratch helper for the *_host convenience calls
 struct ScratchDev {
     void *p = nullptr;

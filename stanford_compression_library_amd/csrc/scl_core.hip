@@ -34,6 +34,23 @@ extern "C" int scl_device_count(int *count) {
     return n > 0 ? SCL_OK : SCL_E_NODEVICE;
 }
 
+int scl_current_device(void) {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
+}
+
+int scl_check_device(int model_device, const char *what) {
+    const int cur = scl_current_device();
+    if (cur == model_device) return SCL_OK;
+    scl_set_error("%s: the model was created on device %d but the current device is %d (one model per device: "
+                  "create a handle on every GPU that uses it, or hipSetDevice before the call)", what, model_device, cur);
+    return SCL_E_PARAM;
+}
+
 // ---- stream compaction ----------------------------------------------------------------------------
 // Layout of one output record:
 //   DENSE : ceil(nbits/8) bytes, stream left-aligned, zero tail bits

@@ -170,6 +170,7 @@ extern "C" int scl_range_model_create(const uint32_t *h_freq, uint32_t K, uint32
                 "range_model_create: total_freq %llu > BOTTOM = 2^%u (assert at range_coder.py:85)",
                 (unsigned long long)M, precision - 16);
     scl_range_model *m = new scl_range_model();
+    m->device = scl_current_device();
     m->dev.K = K;
     m->dev.P = precision;
     m->dev.size_bits = size_bits;
@@ -226,6 +227,7 @@ extern "C" int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d
                                       uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
                                       uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "range_encode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "range_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
                 "range_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "range_encode_batch: d_out must be 16-byte aligned");
@@ -253,6 +255,7 @@ extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d
                                       uint32_t *d_consumed, uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "range_decode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "range_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "range_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     const u32 threads = 256;

@@ -24,6 +24,7 @@ struct RangeFastDev {
 };
 
 struct scl_range_model {
+    int device;  // hipGetDevice() at create: the tables live there (scl_check_device)
     RangeDev dev;
     RangeFastDev fdev;
     u32 fast;

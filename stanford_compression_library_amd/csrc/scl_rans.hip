@@ -168,6 +168,7 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
     unsigned __int128 H = (L << b) - 1;
     SCL_REQUIRE((H >> 63) == 0, "rans_model_create: H >= 2^63 overflows the reference's int64 state (quirk Q7)");
     scl_rans_model *m = new scl_rans_model();
+    m->device = scl_current_device();
     ::memset((void *)m, 0, sizeof(*m));
     m->dev.K = K;
     m->dev.b = b;
@@ -262,6 +263,7 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
     int rc = check_batch_args("rans_encode_batch", m, d_sym, d_out, d_out_bit_offset, d_out_nbits, out_stride);
     if (rc) return rc;
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "rans_encode_batch: d_out must be 16-byte aligned");
+    if (int rc_dev = scl_check_device(m->device, "rans_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride * 8 < (1ull << 32), "rans_encode_batch: slot larger than 512 MiB");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -292,6 +294,7 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
                                      uint32_t *d_consumed, uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "rans_decode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "rans_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "rans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -43,6 +43,7 @@ struct RansFastBDev {
 };
 
 struct scl_rans_model {
+    int device;  // hipGetDevice() at create: the tables live there (scl_check_device)
     RansDev dev;
     RansFastDev fdev;
     RansFastBDev fbdev;

@@ -167,6 +167,37 @@ __global__ void __launch_bounds__(256) tans_decode_kernel(TansDev P, const u8 *_
 // ---- host API -------------------------------------------------------------------------------------------
 #define TANS_LDS_BUDGET (64u * 1024u)
 
+// builds base_encode_step_table / base_decode_step_table / the per-symbol tables on the device, once
+static int tans_ensure_tables(const scl_tans_model *cm) {
+    scl_tans_model *m = const_cast<scl_tans_model *>(cm);
+    std::lock_guard<std::mutex> guard(m->build_lock);
+    if (m->built) return SCL_OK;
+    const u64 L = m->dev.L;
+    const u32 K = m->dev.K;
+    hipError_t e = hipSuccess;
+    u32 **tabs[] = {&m->d_enc, &m->d_dec_sym, &m->d_dec_xs};
+    for (u32 **p : tabs)
+        if (e == hipSuccess && !*p) e = hipMalloc((void **)p, L * sizeof(u32));
+    if (e == hipSuccess) {
+        const u32 n_thr = (u32)(L > K ? L : K);
+        hipLaunchKernelGGL(tans_build_tables, dim3((n_thr + 255) / 256), dim3(256), 0, 0, K, m->dev.M, m->dev.RF,
+                           m->dev.m_log2, m->dev.nsb, m->d_freq, m->d_cum, m->d_enc, m->d_nbits, m->d_thresh,
+                           m->d_dec_sym, m->d_dec_xs);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        scl_set_error("tans: device table build (%llu entries) failed: %s", (unsigned long long)L, hipGetErrorString(e));
+        return SCL_E_HIP;
+    }
+    m->dev.d_enc = m->d_enc;
+    m->dev.d_dec_sym = m->d_dec_sym;
+    m->dev.d_dec_xs = m->d_dec_xs;
+    m->built = 1;
+    return SCL_OK;
+}
+
 extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor, uint32_t size_bits,
                                      scl_tans_model **out) {
     SCL_REQUIRE(out, "tans_model_create: null output");
@@ -203,6 +234,7 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
         return SCL_E_PARAM;
     }
     scl_tans_model *m = new scl_tans_model();
+    m->device = scl_current_device();
     m->rans = rans;
     m->tables = (L <= (1ull << 26)) ? 1u : 0u;
     m->dev.K = K;
@@ -229,33 +261,23 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     alloc(&m->d_cum, 256);
     alloc(&m->d_nbits, 256);
     alloc(&m->d_thresh, 256);
-    alloc(&m->d_enc, m->tables ? L : 1);
-    alloc(&m->d_dec_sym, m->tables ? L : 1);
-    alloc(&m->d_dec_xs, m->tables ? L : 1);
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, h_freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
-    if (e == hipSuccess && m->tables) {
-        const u32 n_thr = (u32)(L > K ? L : K);
-        hipLaunchKernelGGL(tans_build_tables, dim3((n_thr + 255) / 256), dim3(256), 0, 0, K, (u32)M, (u32)range_factor,
-                           m->dev.m_log2, m->dev.nsb, m->d_freq, m->d_cum, m->d_enc, m->d_nbits, m->d_thresh,
-                           m->d_dec_sym, m->d_dec_xs);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
     if (e != hipSuccess) {
-        scl_set_error("tans_model_create: device table build failed: %s", hipGetErrorString(e));
+        scl_set_error("tans_model_create: device table upload failed: %s", hipGetErrorString(e));
         scl_tans_model_destroy(m);
         return SCL_E_HIP;
     }
     m->dev.d_freq = m->d_freq;
     m->dev.d_cum = m->d_cum;
-    m->dev.d_enc = m->d_enc;
     m->dev.d_nbits = m->d_nbits;
     m->dev.d_thresh = m->d_thresh;
-    m->dev.d_dec_sym = m->d_dec_sym;
-    m->dev.d_dec_xs = m->d_dec_xs;
     m->dev.lds_tables = (m->tables && 2 * L * sizeof(u32) <= TANS_LDS_BUDGET) ? 1u : 0u;
-    const int rc = m->tables ? tans_fast_build_tables(m, h_freq, cum) : SCL_OK;
+    // A model with a companion rANS handle is served by the table-free kernels: its 3 x L-entry tables (768 MiB at
+    // 2^26 entries) are only built if somebody asks for them (scl_tans_model_tables, or rows the tuned kernels
+    // cannot take) -- tans_ensure_tables.
+    int rc = (m->tables && !m->rans) ? tans_ensure_tables(m) : SCL_OK;
+    if (rc == SCL_OK && m->tables && !m->rans) rc = tans_fast_build_tables(m, h_freq, cum);
     if (rc != SCL_OK) {
         scl_tans_model_destroy(m);
         return rc;
@@ -301,6 +323,7 @@ extern "C" int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, u
     SCL_REQUIRE(m, "tans_model_tables: null model");
     SCL_REQUIRE(m->tables, "tans_model_tables: RANGE_FACTOR*M = %llu entries are above the 2^26-entry budget; this "
                            "model runs on the table-free rANS kernels", (unsigned long long)m->dev.L);
+    if (int rc = tans_ensure_tables(m)) return rc;
     const u64 Lb = (u64)m->dev.L * sizeof(u32), Kb = (u64)m->dev.K * sizeof(u32);
     if (h_enc) SCL_HIP_TRY(hipMemcpy(h_enc, m->d_enc, Lb, hipMemcpyDeviceToHost));
     if (h_nbits) SCL_HIP_TRY(hipMemcpy(h_nbits, m->d_nbits, Kb, hipMemcpyDeviceToHost));
@@ -315,6 +338,7 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
                                      uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
                                      uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "tans_encode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "tans_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
                 "tans_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "tans_encode_batch: d_out must be 16-byte aligned");
@@ -335,6 +359,7 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
     }
     SCL_REQUIRE(m->tables, "tans_encode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned symbol rows and slots of scl_tans_slot_bytes");
+    if (int rc = tans_ensure_tables(m)) return rc;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (768 + (m->dev.lds_tables ? m->dev.L : 0)) * sizeof(u32);
@@ -351,6 +376,7 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                                      uint32_t *d_consumed, uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "tans_decode_batch: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "tans_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "tans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
@@ -367,6 +393,7 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
     }
     SCL_REQUIRE(m->tables, "tans_decode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned buffers");
+    if (int rc = tans_ensure_tables(m)) return rc;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (m->dev.lds_tables ? 2 * m->dev.L : 4) * sizeof(u32);
@@ -382,7 +409,7 @@ static int tans_run_enc(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u6
                         u32 *d_nbits, u32 *d_status, void *, u64) {
     const scl_tans_model *m = (const scl_tans_model *)model;
     // one row: its stride is free, and a multiple of 16 lets a table-less model reach the kernels that serve it
-    return scl_tans_encode_batch(m, d_sym, m->tables ? n : scl_round_up(n, 16), nullptr, n, 1, d_out, out_stride,
+    return scl_tans_encode_batch(m, d_sym, (m->tables && !m->rans) ? n : scl_round_up(n, 16), nullptr, n, 1, d_out, out_stride,
                                  d_bit_off, d_nbits, d_status, nullptr);
 }
 static u64 tans_slot(const void *model, u64 n) { return scl_tans_slot_bytes((const scl_tans_model *)model, n); }

@@ -1,6 +1,7 @@
 // scl_tans_internal.h -- model layout shared by scl_tans.hip (table builder, generic kernels, host API) and
 // scl_tans_fast.hip (the gfx950 fast path).  Internal to csrc/.
 #pragma once
+#include <mutex>
 #include "scl_common.h"
 
 struct TansDev {
@@ -30,6 +31,7 @@ struct TansFastDev {
 struct scl_rans_model;
 
 struct scl_tans_model {
+    int device;  // hipGetDevice() at create: the tables live there (scl_check_device)
     TansDev dev;
     TansFastDev fdev;
     u32 fast;
@@ -38,7 +40,9 @@ struct scl_tans_model {
     // the 2^26-entry budget (the reference's default RANGE_FACTOR = 2^16 with M = 4096 asks for 2^28 entries) that
     // is the only route and no lookup tables are built (`tables` = 0)
     scl_rans_model *rans;
-    u32 tables;
+    u32 tables;  // the lookup tables CAN be built (RANGE_FACTOR * M <= 2^26) ...
+    u32 built;   // ... and have been (eagerly without a companion rANS model, else on first use: tans_ensure_tables)
+    std::mutex build_lock;
     u32 max_bits_per_symbol;
     u32 *d_freq, *d_cum, *d_enc, *d_nbits, *d_thresh, *d_dec_sym, *d_dec_xs;
     uint4 *d_fenc_sym;
