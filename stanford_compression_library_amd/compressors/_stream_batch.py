@@ -5,6 +5,11 @@ record per block, scl/core/data_encoder_decoder.py:57-69 and :118-144).  The sta
 independent, so here the whole stream becomes ONE batched launch (one lane per block) followed by the device-side
 framing pass (``scl_streams_compact`` with ``SCL_COMPACT_FRAMED``), and the file bytes are written in one go.
 The resulting file is byte-identical to the per-block loop (and to the reference's ``EncodedBlockWriter``).
+
+Only ``write_block`` / ``get_block`` are part of the reference's writer / reader contract: a writer without
+``write_framed_bytes`` or a reader without ``file_reader`` gets the inherited per-block loop.  Streams are processed in
+bounded batches (``MAX_BATCH_BYTES`` of symbols at a time), and a block header's size field -- untrusted input on the
+decode side -- is checked against ``MAX_BLOCK_SYMBOLS`` before anything is allocated for it.
 """
 from __future__ import annotations
 
@@ -12,21 +17,32 @@ import numpy as np
 
 from ..backend.models import compact
 
+MAX_BATCH_BYTES = 1 << 28     # symbols per launch: bounds host + device memory whatever the stream length
+MAX_BLOCK_SYMBOLS = 1 << 26   # largest block size a decoder accepts from a header before allocating for it
+
 
 class BatchedStreamEncoderMixin:
     """expects ``self._batch_model()`` -> (device model, symbol->index dict)"""
 
     def encode(self, data_stream, block_size: int, encode_writer):
+        if not hasattr(encode_writer, "write_framed_bytes"):
+            return super().encode(data_stream, block_size, encode_writer)  # any writer with write_block
+        per_batch = max(1, MAX_BATCH_BYTES // max(1, block_size))
+        while True:
+            blocks = []
+            while len(blocks) < per_batch:
+                blk = data_stream.get_block(block_size)
+                if blk is None:
+                    break
+                blocks.append(blk)
+            if blocks:
+                self._encode_batch(blocks, block_size, encode_writer)
+            if len(blocks) < per_batch:
+                return
+
+    def _encode_batch(self, blocks, block_size: int, encode_writer):
         import torch
 
-        blocks = []
-        while True:
-            blk = data_stream.get_block(block_size)
-            if blk is None:
-                break
-            blocks.append(blk)
-        if not blocks:
-            return
         model, index_of = self._batch_model()
         n = len(blocks)
         width = (block_size + 15) // 16 * 16
@@ -50,19 +66,38 @@ class BatchedStreamDecoderMixin:
     """expects ``self._batch_model()`` -> (device model, alphabet list) and ``self._size_bits``"""
 
     def decode(self, encode_reader, output_stream):
+        if not hasattr(encode_reader, "file_reader"):
+            return super().decode(encode_reader, output_stream)  # any reader with get_block
+        f = encode_reader.file_reader
+        while True:
+            # one batch = whole framed records up to MAX_BATCH_BYTES (at least one record)
+            chunks, size = [], 0
+            while size < MAX_BATCH_BYTES:
+                header = f.read(4)
+                if len(header) == 0:
+                    break
+                assert len(header) == 4, "truncated block file"
+                payload = int.from_bytes(header, "big")
+                body = f.read(payload)
+                assert len(body) == payload and payload >= 1, "truncated block file"
+                chunks += [header, body]
+                size += 4 + payload
+            if not chunks:
+                return
+            self._decode_batch(np.frombuffer(b"".join(chunks), dtype=np.uint8), output_stream)
+
+    def _decode_batch(self, raw, output_stream):
         import torch
 
         from ..core.data_block import DataBlock
 
-        raw = np.frombuffer(encode_reader.file_reader.read(), dtype=np.uint8)
-        if raw.size == 0:
-            return
         # walk the 4-byte block headers on the host (one per block); the payload bits stay where they are
         offs, nbits, pos = [], [], 0
         while pos < raw.size:
             payload = int.from_bytes(raw[pos:pos + 4].tobytes(), "big")
             assert pos + 4 + payload <= raw.size, "truncated block file"
             pad = int(raw[pos + 4]) >> 5
+            assert 8 * payload - 3 - pad >= 0, "corrupt block padding"
             offs.append(8 * (pos + 4) + 3 + pad)
             nbits.append(8 * payload - 3 - pad)
             pos += 4 + payload
@@ -76,6 +111,7 @@ class BatchedStreamDecoderMixin:
         for o in offs:
             bits = np.unpackbits(raw[o // 8:(o + sb + 7) // 8 + 1])[o % 8:o % 8 + sb]
             cap = max(cap, int("".join(map(str, bits.tolist())), 2))
+        assert cap <= MAX_BLOCK_SYMBOLS, f"block header announces {cap} symbols (limit {MAX_BLOCK_SYMBOLS})"
         sym, lens, used, status = model.decode_batch(buf, torch.tensor(offs, dtype=torch.int64, device=dev),
                                                      torch.tensor(nbits, dtype=torch.int32, device=dev), max(cap, 1))
         torch.cuda.synchronize()

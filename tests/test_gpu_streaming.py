@@ -118,3 +118,54 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
     assert out["value"] > 0 and out["config"]["chunks_per_gpu"] == 4096
+
+
+def test_stream_driver_custom_writer_and_bounded_batches(tmp_path, monkeypatch):
+    """(a) a writer / reader that only offers the reference's contract (write_block / get_block) gets the per-block
+    loop; (b) streams longer than one batch are cut into several launches; both give the same file bytes"""
+    from stanford_compression_library_amd.compressors import _stream_batch
+    from stanford_compression_library_amd.core.data_stream import ListDataStream
+
+    backend_lib.require_device()
+    data = np.random.default_rng(8).choice(6, size=9_000, p=[.4, .3, .1, .1, .05, .05]).tolist()
+    fr = Frequencies(dict(zip(range(6), [40, 30, 10, 10, 5, 5])))
+    params = rANSParams(fr)
+
+    class PlainWriter:  # only write_block, like any user-defined writer the reference accepts
+        def __init__(self):
+            self.blocks = []
+
+        def write_block(self, bits):
+            self.blocks.append(bits)
+
+    class PlainReader:
+        def __init__(self, blocks):
+            self.blocks = list(blocks)
+
+        def get_block(self):
+            return self.blocks.pop(0) if self.blocks else None
+
+    w = PlainWriter()
+    rANSEncoder(params).encode(ListDataStream(list(data)), 500, w)
+    assert len(w.blocks) == 18
+    path = os.path.join(tmp_path, "a.bin")
+    with EncodedBlockWriter(path) as fw:
+        for b in w.blocks:
+            fw.write_block(b)
+    out = ListDataStream([])
+    rANSDecoder(params).decode(PlainReader(w.blocks), out)
+    assert out.input_list == data
+    # several launches per stream: 4 blocks of 500 symbols per batch
+    monkeypatch.setattr(_stream_batch, "MAX_BATCH_BYTES", 2000)
+    path2 = os.path.join(tmp_path, "b.bin")
+    with EncodedBlockWriter(path2) as fw:
+        rANSEncoder(params).encode(ListDataStream(list(data)), 500, fw)
+    assert open(path, "rb").read() == open(path2, "rb").read()
+    out = ListDataStream([])
+    with EncodedBlockReader(path2) as r:
+        rANSDecoder(params).decode(r, out)
+    assert out.input_list == data
+    # a corrupt header that announces an absurd block size is refused before anything is allocated for it
+    monkeypatch.setattr(_stream_batch, "MAX_BLOCK_SYMBOLS", 400)
+    with EncodedBlockReader(path2) as r, pytest.raises(AssertionError):
+        rANSDecoder(params).decode(r, ListDataStream([]))
