@@ -13,6 +13,9 @@
 // The ring of a workgroup must start at LDS offset 0 (addresses wrap with a single AND).
 #pragma once
 #include "scl_common.h"
+#ifndef RF_ABLATE
+#define RF_ABLATE 0
+#endif
 
 
 // Instruction selection follows profiles/r01_ubench_valu_issue_cost.txt: on gfx950 only
@@ -151,6 +154,135 @@ struct AnsBackWriter {
         const u32 words = nfl + np;
         if (nacc) end32[-(i64)words - 1] = __builtin_bswap32(lo);  // zero bits in front of the stream
         return (u64)words * 32 + nacc;
+    }
+};
+
+// Window form of the back writer (round 2).  Same ring, same flush, same stream; what changes is how the bits get
+// there.  The pending bits are the TOP n bits of a 64-bit window hi:lo, newest on top:
+//   push(x, k):  lo = alignbit(hi, lo, k);  hi = alignbit(x, hi, k);  n += k
+//                v_alignbit takes the low k bits of its first operand by itself: no field extraction (v_bfe), no merging
+//                of two fields, no shift of the field to its place in the accumulator;
+//   check():     every two symbols (n <= 32 + 2*13 < 64).  n >= 33: the oldest 32 bits, alignbit(hi, lo, 64 - n), are a
+//                complete word; the rest of the window stays where it is (top-aligned), n -= 32.  n is kept negated (nn =
+//                -n) so that the word's shift amount is nn itself: v_alignbit reads the low 5 bits, (-n) mod 32 = 64 - n
+//                for 33 <= n <= 63.
+// The block that emits a word runs for the whole wave whenever ANY lane has one (practically every pair), so its length
+// counts twice: alignbit + byte swap + ring address update (2) + count update, against sub + shift + swap + address (2) +
+// count + two copies of the accumulator before (per pair: 5 instructions less, and two v_bfe + two v_lshl_or become four
+// v_alignbit of the same issue cost).
+template <int THREADS>
+struct AnsBackWriterW {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
+    u32 hi, lo;  // the window
+    int nn;      // minus the number of pending bits
+    u32 ra;      // LDS byte address of the ring word that completes next (thread column, moves DOWN a row per word)
+    u32 fa;      // LDS byte address of the lowest row of the oldest unflushed group of 16 words
+    u32 nfl;     // words already stored to memory
+    u8 *slot_end;
+    uint4 held[4];
+    u32 have_held;
+
+    __device__ __forceinline__ u32 pend() const { return ((fa + 15 * THREADS * 4 - ra) & (RING_BYTES - 1)) / (THREADS * 4); }
+
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
+        hi = lo = 0;
+        nn = 0;
+        ra = tid * 4 + 31 * THREADS * 4;
+        fa = tid * 4 + 16 * THREADS * 4;
+        nfl = 0;
+        slot_end = slot_end_;
+        have_held = 0;
+        held[0] = held[1] = held[2] = held[3] = make_uint4(0, 0, 0, 0);
+    }
+    // the low k bits of v go in front of the stream; k < 32, any bits of v above bit k are ignored
+    __device__ __forceinline__ void push(u32 v, u32 k) {
+        lo = __builtin_amdgcn_alignbit(hi, lo, k);
+        hi = __builtin_amdgcn_alignbit(v, hi, k);
+        nn -= (int)k;
+    }
+    // call after at most 26 pushed bits
+    __device__ __forceinline__ void check(char *lds) {
+        if (nn < -32) {
+            const u32 word = __builtin_amdgcn_alignbit(hi, lo, (u32)nn);
+#if !(RF_ABLATE & 4)  // timing experiment 4: no ring write
+            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32(word);
+#else
+            asm volatile("" : : "v"(word));
+#endif
+            ra = (ra - THREADS * 4) & (RING_BYTES - 1);
+            nn += 32;
+        }
+    }
+    __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
+        if (w > 16) {
+            push(v, 16);
+            check(lds);
+            push(v >> 16, w - 16);
+        } else {
+            push(v, w);
+        }
+        check(lds);
+    }
+    // identical to AnsBackWriter::maybe_flush: 16 pending words leave the ring at a time, the first 64-byte half of a
+    // line waits in registers until the second half is ready.  Call at least every 32 symbols.
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        if (pend() >= 16) {
+            const char *r = lds + fa;
+#define SCL_RING_W(j) (*reinterpret_cast<const u32 *>(r + (j) * THREADS * 4))
+#define SCL_RING_Q(i) make_uint4(SCL_RING_W(4 * (i)), SCL_RING_W(4 * (i) + 1), SCL_RING_W(4 * (i) + 2), SCL_RING_W(4 * (i) + 3))
+            if (!have_held) {
+                held[0] = SCL_RING_Q(0);
+                held[1] = SCL_RING_Q(1);
+                held[2] = SCL_RING_Q(2);
+                held[3] = SCL_RING_Q(3);
+                have_held = 1;
+            } else {
+                const uint4 q0 = SCL_RING_Q(0), q1 = SCL_RING_Q(1), q2 = SCL_RING_Q(2), q3 = SCL_RING_Q(3);
+                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
+#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
+                p[0] = q0;
+                p[1] = q1;
+                p[2] = q2;
+                p[3] = q3;
+                p[4] = held[0];
+                p[5] = held[1];
+                p[6] = held[2];
+                p[7] = held[3];
+#elif RF_ABLATE & 8  // timing experiment 8 (with 2): ONE 16-byte store per line instead of eight
+                p[0] = make_uint4(q0.x ^ held[0].x, q1.x ^ held[1].y, q2.x ^ held[2].z, q3.x ^ held[3].w);
+#elif RF_ABLATE & 16  // timing experiment 16 (with 2): the eight stores of a line all go to its first 16 bytes
+                p[0] = q0; p[0] = q1; p[0] = q2; p[0] = q3; p[0] = held[0]; p[0] = held[1]; p[0] = held[2]; p[0] = held[3];
+#else
+                asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
+#endif
+                have_held = 0;
+            }
+#undef SCL_RING_Q
+#undef SCL_RING_W
+            nfl += 16;
+            fa ^= 16 * THREADS * 4;
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds) {
+        maybe_flush(lds);
+        if (have_held) {
+            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)nfl);
+            p[0] = held[0];
+            p[1] = held[1];
+            p[2] = held[2];
+            p[3] = held[3];
+        }
+        u32 *end32 = reinterpret_cast<u32 *>(slot_end);
+        u32 a = fa + 15 * THREADS * 4;
+        const u32 np = pend();
+        for (u32 j = 0; j < np; ++j) {
+            end32[-(i64)(nfl + j) - 1] = *reinterpret_cast<const u32 *>(lds + a);
+            a -= THREADS * 4;
+        }
+        const u32 words = nfl + np;
+        const u32 n = (u32)(-nn);  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
+        if (n) end32[-(i64)words - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
+        return (u64)words * 32 + n;
     }
 };
 

@@ -48,7 +48,24 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 //           t mod 32 for every w, so the scattered ds_write_b32 never conflict), and leave as 64
 //           contiguous bytes (4 back-to-back 16-byte stores) once 16 words are pending.
 #define RF_RING_BYTES (32 * RF_THREADS * 4)
+// RF_ENC_WINDOW = 1 (default): fields go straight from the state register into a 64-bit window (AnsBackWriterW);
+// 0: the round-1 form (extract the field, merge two fields, add them to a 32-bit accumulator)
+#ifndef RF_ENC_WINDOW
+#define RF_ENC_WINDOW 1
+#endif
+#if RF_ENC_WINDOW
+typedef AnsBackWriterW<RF_THREADS> EncOut;
+#else
 typedef AnsBackWriter<RF_THREADS> EncOut;
+#endif
+
+// v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
+// half-rate instructions); one full-rate add feeding the multiply-add is cheaper
+__device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
+    u32 d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 struct EncSym {
     u32 bits, k;
@@ -73,6 +90,17 @@ __device__ __forceinline__ EncSym rf_encode_entry(u32 &x, const uint4 e, u32 msh
     return r;
 }
 
+// window form: the field is never extracted -- push() takes the low k bits of x by itself
+template <int MSH_T>
+__device__ __forceinline__ void rf_encode_entry_w(u32 &x, const uint4 e, u32 msh_rt, AnsBackWriterW<RF_THREADS> &o) {
+    const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
+    const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
+    const u32 k = (e.w >> 24) - neg;
+    const u32 q = rf_umulhi(MSH_T ? x : (x << (msh_rt >> 8)), e.x) >> (MSH - neg);
+    o.push(x, k);
+    x = rf_mad24(q, e.w, (x >> k) + e.z);  // v_mad_u32_u24 reads only the low 24 bits of e.w
+}
+
 template <int MSH_T>
 __device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char *tab, u32 msh_rt) {
     return rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + addr), msh_rt);
@@ -81,6 +109,13 @@ __device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char 
 struct Entries4 {
     uint4 e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
+#if RF_ABLATE & 1  // timing experiment: no table read (entries made up from the symbol word)
+        e[0] = make_uint4(0x20000000u | w, 0x18000000u, w & 0xFFFu, 16u | (9u << 24));
+        e[1] = make_uint4(0x20000000u | (w >> 3), 0x18000000u, (w >> 8) & 0xFFFu, 16u | (9u << 24));
+        e[2] = make_uint4(0x20000000u | (w >> 5), 0x18000000u, (w >> 16) & 0xFFFu, 16u | (9u << 24));
+        e[3] = make_uint4(0x20000000u | (w >> 7), 0x18000000u, (w >> 20) & 0xFFFu, 16u | (9u << 24));
+        return;
+#endif
         e[0] = *reinterpret_cast<const uint4 *>(tab + ((w << 4) & 0xFF0u));
         e[1] = *reinterpret_cast<const uint4 *>(tab + ((w >> 4) & 0xFF0u));
         e[2] = *reinterpret_cast<const uint4 *>(tab + ((w >> 12) & 0xFF0u));
@@ -107,6 +142,14 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u3
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
+#if RF_ENC_WINDOW
+        rf_encode_entry_w<MSH_T>(x, cur.e[0], msh_rt, o);
+        rf_encode_entry_w<MSH_T>(x, cur.e[1], msh_rt, o);
+        o.check(lds);
+        rf_encode_entry_w<MSH_T>(x, cur.e[2], msh_rt, o);
+        rf_encode_entry_w<MSH_T>(x, cur.e[3], msh_rt, o);
+        o.check(lds);
+#else
         const EncSym s0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt);
         const EncSym s1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt);
         // the later symbol's field goes in front (more significant side) of the earlier one's
@@ -114,6 +157,7 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u3
         const EncSym s2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt);
         const EncSym s3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt);
         o.put(lds, (s3.bits << s2.k) | s2.bits, s2.k + s3.k);
+#endif
     }
 }
 
@@ -185,8 +229,13 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
+#if RF_ENC_WINDOW
+        rf_encode_entry_w<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o);
+        o.check(lds);
+#else
         const EncSym s = rf_encode_symbol<MSH_T>(x, a, tab, msh_rt);
         o.put(lds, s.bits, s.k);
+#endif
         if ((i & 15u) == 15u) o.maybe_flush(lds);
     }
     o.maybe_flush(lds);
