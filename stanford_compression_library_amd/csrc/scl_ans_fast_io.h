@@ -157,59 +157,70 @@ struct AnsBackWriter {
     }
 };
 
-// Window form of the back writer (round 2).  Same ring, same flush, same stream; what changes is how the bits get
-// there.  The pending bits are the TOP n bits of a 64-bit window hi:lo, newest on top:
-//   push(x, k):  lo = alignbit(hi, lo, k);  hi = alignbit(x, hi, k);  n += k
-//                v_alignbit takes the low k bits of its first operand by itself: no field extraction (v_bfe), no merging
-//                of two fields, no shift of the field to its place in the accumulator;
-//   check():     every two symbols (n <= 32 + 2*13 < 64).  n >= 33: the oldest 32 bits, alignbit(hi, lo, 64 - n), are a
-//                complete word; the rest of the window stays where it is (top-aligned), n -= 32.  n is kept negated (nn =
-//                -n) so that the word's shift amount is nn itself: v_alignbit reads the low 5 bits, (-n) mod 32 = 64 - n
-//                for 33 <= n <= 63.
-// The block that emits a word runs for the whole wave whenever ANY lane has one (practically every pair), so its length
-// counts twice: alignbit + byte swap + ring address update (2) + count update, against sub + shift + swap + address (2) +
-// count + two copies of the accumulator before (per pair: 5 instructions less, and two v_bfe + two v_lshl_or become four
-// v_alignbit of the same issue cost).
+// ---------------------------------------------------------------------------------------------------------------
+// Round-2 back writer: 64-bit bit window -> per-lane LDS ring of 64 words -> whole 128-byte lines stored by quads.
+//
+// (1) Bits.  The pending bits are the TOP n bits of a 64-bit window hi:lo, newest on top:
+//       push(x, k):  lo = alignbit(hi, lo, k);  hi = alignbit(x, hi, k);  n += k
+//     v_alignbit takes the low k bits of its first operand by itself: no field extraction (v_bfe), no merging of two
+//     fields, no shift of the field to its place in an accumulator.  check() every two symbols (n <= 32 + 2*13 < 64):
+//     n >= 33 means the oldest 32 bits, alignbit(hi, lo, 64 - n), are a complete word; the rest of the window stays
+//     where it is (top-aligned), n -= 32.  n is kept negated (nn = -n) so that the word's shift amount is nn itself
+//     (v_alignbit reads the low 5 bits: (-n) mod 32 = 64 - n for 33 <= n <= 63).
+// (2) Ring.  256 bytes per lane, [thread][word] with a 272-byte thread stride: the two halves are two 128-byte line
+//     buffers holding words in MEMORY order (the stream grows downwards, so the write offset walks 124, 120, .. 0, 252,
+//     .. 128, 124, ..: (wl - 4) & 252).  A lane's scattered 4-byte writes now collide in the banks now and then
+//     (bank = (4 t + w) mod 32), which ds_write_b32 mostly hides; what the layout buys is that a 16-byte piece of a line
+//     is ONE aligned ds_read_b128 -- for any lane.
+// (3) Stores.  What bounds a lane-per-chunk coder on this chip is the SHAPE of its write requests: with the same
+//     lines, the same bytes and no arithmetic at all, lanes storing their own lines (8 x 16 bytes) take 0.58 ms per GiB
+//     batch, four lanes per 64-byte half line 0.52, eight lanes per whole line 0.42 (tools/ubench/linecopy3.hip; the read
+//     shape makes no difference).  The round-1 encoder (0.59 ms) sat exactly on the first figure.  So a line is stored by
+//     the four lanes of the source lane's quad, 2 x 16 bytes each, as two back-to-back 64-byte requests -- without
+//     synchronising the lanes, which complete their lines at data-dependent times: at a flush point (wave-uniform code,
+//     every 64 symbols) four rounds r = 0..3; in round r the quads whose lane r has a complete line store it; lane j
+//     of the quad reads the pieces j and j + 4 of the SOURCE lane's line buffer (two ds_read_b128; the source's
+//     addresses come by DPP quad broadcast) and stores them at the source's position + 16 j (+ 64).
+//     That needs a whole line buffered while the next one fills (64-word ring = 2 workgroups per CU instead of 4: measured
+//     neutral, the kernel issues as fast with 2 waves per SIMD) and every lane of the wave alive until the last flush
+//     point: whole waves of equally long chunks; otherwise flush_lane(), the lane's own eight 16-byte stores.
+template <int R>
+__device__ __forceinline__ u32 scl_quad_bcast(u32 v) {  // value of lane R of this lane's quad (quad_perm:[R,R,R,R])
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, R * 0x55, 0xF, 0xF, true);
+}
 template <int THREADS>
-struct AnsBackWriterW {
-    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
-    u32 hi, lo;  // the window
-    int nn;      // minus the number of pending bits
-    u32 ra;      // LDS byte address of the ring word that completes next (thread column, moves DOWN a row per word)
-    u32 fa;      // LDS byte address of the lowest row of the oldest unflushed group of 16 words
-    u32 nfl;     // words already stored to memory
-    u8 *slot_end;
-    uint4 held[4];
-    u32 have_held;
+struct AnsBackWriterL {
+    static constexpr u32 LANE_BYTES = 272;                   // 256-byte ring + 16 bytes of skew
+    static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup
+    u32 hi, lo;   // the window
+    int nn;       // minus the number of pending bits
+    u32 wl;       // ring offset (bytes, 0..252) of the word that completes next
+    u32 th4;      // 124 or 252: offset of the FIRST word of the oldest unflushed line (top of its half)
+    u32 base;     // tid * LANE_BYTES
+    u32 goff;     // byte offset (from the workgroup's output base) of the END of the next line to store
+    u32 goff0;    // ... of the slot end
 
-    __device__ __forceinline__ u32 pend() const { return ((fa + 15 * THREADS * 4 - ra) & (RING_BYTES - 1)) / (THREADS * 4); }
+    __device__ __forceinline__ u32 pend4() const { return (th4 - wl) & 255u; }  // 4 * completed words not yet stored (< 256)
 
-    __device__ __forceinline__ void init(u32 tid, u8 *slot_end_) {
+    __device__ __forceinline__ void init(u32 tid, u32 slot_end_off) {
         hi = lo = 0;
         nn = 0;
-        ra = tid * 4 + 31 * THREADS * 4;
-        fa = tid * 4 + 16 * THREADS * 4;
-        nfl = 0;
-        slot_end = slot_end_;
-        have_held = 0;
-        held[0] = held[1] = held[2] = held[3] = make_uint4(0, 0, 0, 0);
+        wl = 124;
+        th4 = 124;
+        base = tid * LANE_BYTES;
+        goff = goff0 = slot_end_off;
     }
-    // the low k bits of v go in front of the stream; k < 32, any bits of v above bit k are ignored
+    // the low k bits of v go in front of the stream; k < 32, bits of v above bit k are ignored
     __device__ __forceinline__ void push(u32 v, u32 k) {
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
         hi = __builtin_amdgcn_alignbit(v, hi, k);
         nn -= (int)k;
     }
-    // call after at most 26 pushed bits
-    __device__ __forceinline__ void check(char *lds) {
+    __device__ __forceinline__ void check(char *lds) {  // after at most 26 pushed bits
         if (nn < -32) {
             const u32 word = __builtin_amdgcn_alignbit(hi, lo, (u32)nn);
-#if !(RF_ABLATE & 4)  // timing experiment 4: no ring write
-            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32(word);
-#else
-            asm volatile("" : : "v"(word));
-#endif
-            ra = (ra - THREADS * 4) & (RING_BYTES - 1);
+            *reinterpret_cast<u32 *>(lds + base + wl) = __builtin_bswap32(word);
+            wl = (wl - 4u) & 252u;
             nn += 32;
         }
     }
@@ -223,66 +234,61 @@ struct AnsBackWriterW {
         }
         check(lds);
     }
-    // identical to AnsBackWriter::maybe_flush: 16 pending words leave the ring at a time, the first 64-byte half of a
-    // line waits in registers until the second half is ready.  Call at least every 32 symbols.
-    __device__ __forceinline__ void maybe_flush(char *lds) {
-        if (pend() >= 16) {
-            const char *r = lds + fa;
-#define SCL_RING_W(j) (*reinterpret_cast<const u32 *>(r + (j) * THREADS * 4))
-#define SCL_RING_Q(i) make_uint4(SCL_RING_W(4 * (i)), SCL_RING_W(4 * (i) + 1), SCL_RING_W(4 * (i) + 2), SCL_RING_W(4 * (i) + 3))
-            if (!have_held) {
-                held[0] = SCL_RING_Q(0);
-                held[1] = SCL_RING_Q(1);
-                held[2] = SCL_RING_Q(2);
-                held[3] = SCL_RING_Q(3);
-                have_held = 1;
-            } else {
-                const uint4 q0 = SCL_RING_Q(0), q1 = SCL_RING_Q(1), q2 = SCL_RING_Q(2), q3 = SCL_RING_Q(3);
-                uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)(nfl + 16));
-#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
-                p[0] = q0;
-                p[1] = q1;
-                p[2] = q2;
-                p[3] = q3;
-                p[4] = held[0];
-                p[5] = held[1];
-                p[6] = held[2];
-                p[7] = held[3];
-#elif RF_ABLATE & 8  // timing experiment 8 (with 2): ONE 16-byte store per line instead of eight
-                p[0] = make_uint4(q0.x ^ held[0].x, q1.x ^ held[1].y, q2.x ^ held[2].z, q3.x ^ held[3].w);
-#elif RF_ABLATE & 16  // timing experiment 16 (with 2): the eight stores of a line all go to its first 16 bytes
-                p[0] = q0; p[0] = q1; p[0] = q2; p[0] = q3; p[0] = held[0]; p[0] = held[1]; p[0] = held[2]; p[0] = held[3];
-#else
-                asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
-#endif
-                have_held = 0;
-            }
-#undef SCL_RING_Q
-#undef SCL_RING_W
-            nfl += 16;
-            fa ^= 16 * THREADS * 4;
+    template <int R>
+    __device__ __forceinline__ void quad_round(const char *lds, u8 *wg_out, u32 f, u32 qj, u32 j16) const {
+        if (scl_quad_bcast<R>(f)) {  // all four lanes of the quads whose lane R has a complete line
+            const u32 half = scl_quad_bcast<R>(th4) - 124u;  // 0 or 128: which half of the source's ring
+            const u32 go_s = scl_quad_bcast<R>(goff);
+            const char *r = lds + (qj + half) + R * LANE_BYTES;
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(r), q1 = *reinterpret_cast<const uint4 *>(r + 64);
+            u8 *p = wg_out + (go_s - 128u + j16);
+            *reinterpret_cast<uint4 *>(p) = q0;
+            *reinterpret_cast<uint4 *>(p + 64) = q1;
         }
     }
-    __device__ __forceinline__ u64 finish(char *lds) {
-        maybe_flush(lds);
-        if (have_held) {
-            uint4 *p = reinterpret_cast<uint4 *>(slot_end - 4 * (u64)nfl);
-            p[0] = held[0];
-            p[1] = held[1];
-            p[2] = held[2];
-            p[3] = held[3];
+    // WAVE-UNIFORM call (all 64 lanes), at least every 64 symbols: <= 26 new words on top of <= 31 pending
+    __device__ __forceinline__ void flush_quad(char *lds, u8 *wg_out, u32 tid) {
+        const u32 f = pend4() >= 128u ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(f != 0)) {
+            const u32 j = tid & 3u;
+            const u32 qj = (tid & ~3u) * LANE_BYTES + 16u * j, j16 = 16u * j;
+            quad_round<0>(lds, wg_out, f, qj, j16);
+            quad_round<1>(lds, wg_out, f, qj, j16);
+            quad_round<2>(lds, wg_out, f, qj, j16);
+            quad_round<3>(lds, wg_out, f, qj, j16);
+            if (f) {
+                goff -= 128u;
+                th4 ^= 128u;
+            }
         }
-        u32 *end32 = reinterpret_cast<u32 *>(slot_end);
-        u32 a = fa + 15 * THREADS * 4;
-        const u32 np = pend();
+    }
+    // the lane's own stores (ragged batches, partial waves): one line = eight 16-byte stores
+    __device__ __forceinline__ void flush_lane(char *lds, u8 *wg_out) {
+        if (pend4() >= 128u) {
+            const uint4 *r = reinterpret_cast<const uint4 *>(lds + base + (th4 - 124u));
+            uint4 *p = reinterpret_cast<uint4 *>(wg_out + (goff - 128u));
+            uint4 q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = q[i];
+            goff -= 128u;
+            th4 ^= 128u;
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds, u8 *wg_out) {  // per lane; returns the stream length in bits
+        flush_lane(lds, wg_out);
+        flush_lane(lds, wg_out);
+        u32 *end32 = reinterpret_cast<u32 *>(wg_out + goff);  // words go below this, newest at the lowest address
+        const u32 np = pend4() >> 2;                         // < 32 now
+        u32 a = th4;
         for (u32 j = 0; j < np; ++j) {
-            end32[-(i64)(nfl + j) - 1] = *reinterpret_cast<const u32 *>(lds + a);
-            a -= THREADS * 4;
+            end32[-(i64)j - 1] = *reinterpret_cast<const u32 *>(lds + base + a);
+            a = (a - 4u) & 252u;
         }
-        const u32 words = nfl + np;
         const u32 n = (u32)(-nn);  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
-        if (n) end32[-(i64)words - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
-        return (u64)words * 32 + n;
+        if (n) end32[-(i64)np - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
+        return (u64)(((goff0 - goff) >> 2) + np) * 32 + n;
     }
 };
 
@@ -370,6 +376,11 @@ struct Line128 {
     __device__ __forceinline__ void load(const uint4 *p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+    // cooperative form: v[i] = this lane's piece of the line of lane (lane & 7) + 8 i; scl_transpose8 completes it
+    __device__ __forceinline__ void load_coop(const uint4 *p, u64 step16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i * step16];
     }
 };
 

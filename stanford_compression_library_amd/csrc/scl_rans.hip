@@ -271,7 +271,7 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     // fast path: qualifying model, 16-byte aligned rows, and slots that cannot overflow (it has no capacity check)
     if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
-        out_stride >= scl_rans_slot_bytes(m, chunk_len))
+        out_stride >= scl_rans_slot_bytes(m, chunk_len) && out_stride < (1ull << 24))  // 256 slots within 32-bit offsets
         rans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                 d_out_bit_offset, d_out_nbits, d_status, st);
     else if (m->fastb && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&

@@ -29,8 +29,11 @@
 #include "scl_rans_internal.h"
 
 #define RF_THREADS 256
-#ifndef RF_ABLATE
-#define RF_ABLATE 0
+#ifndef RF_FLUSH_PHASE
+#define RF_FLUSH_PHASE 1
+#endif
+#ifndef RF_COOP_STORE
+#define RF_COOP_STORE 1  // 0 (timing experiment): every lane stores its own lines
 #endif
 
 __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
@@ -38,26 +41,17 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 // ---------------------------------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------------------------------
-// Memory granularity (profiles/r01_v2_pmc_summary.txt): with one lane per 4 KiB chunk a CU owns 1024
-// open cache lines for input and 1024 for output -- more than L1 and, per XCD, the whole L2.  16-byte
-// lane accesses therefore each became their own fabric request (61 M read + 61 M write requests per
-// GiB, 3.6x / 2.3x traffic amplification).  So every lane now moves whole lines:
-//   input : 128 bytes (one line) per lane as 8 back-to-back 16-byte loads into registers, next line
-//           prefetched while the current one is encoded (ping-pong register buffers);
-//   output: completed big-endian words go to a per-lane ring in LDS (word w of thread t at [w][t]: bank =
-//           t mod 32 for every w, so the scattered ds_write_b32 never conflict), and leave as 64
-//           contiguous bytes (4 back-to-back 16-byte stores) once 16 words are pending.
-#define RF_RING_BYTES (32 * RF_THREADS * 4)
-// RF_ENC_WINDOW = 1 (default): fields go straight from the state register into a 64-bit window (AnsBackWriterW);
-// 0: the round-1 form (extract the field, merge two fields, add them to a 32-bit accumulator)
-#ifndef RF_ENC_WINDOW
-#define RF_ENC_WINDOW 1
-#endif
-#if RF_ENC_WINDOW
-typedef AnsBackWriterW<RF_THREADS> EncOut;
-#else
-typedef AnsBackWriter<RF_THREADS> EncOut;
-#endif
+// Memory granularity (profiles/r01_v2_pmc_summary.txt): with one lane per 4 KiB chunk a CU owns a thousand open cache
+// lines for input and as many for output -- more than L1 and, per XCD, the whole L2 -- so 16-byte lane accesses each
+// became their own fabric request (3.6x / 2.3x traffic).  Every lane therefore moves whole lines:
+//   input : 128 bytes (one line) per lane as 8 back-to-back 16-byte loads into registers, next line prefetched while
+//           the current one is encoded (ping-pong register buffers).  (Loading the wave's 64 lines cooperatively, eight
+//           lanes per line + an 8 x 8 register transpose, was built and measured: 3 % slower -- the read shape is not what
+//           bounds the kernel, tools/ubench/linecopy3.hip.)
+//   output: AnsBackWriterL (scl_ans_fast_io.h): bit window -> 64-word LDS ring per lane -> whole lines stored by quads.
+// LDS per workgroup: 68 KiB ring + 4 KiB table = two workgroups per CU (2 waves per SIMD; 4 measured the same).
+typedef AnsBackWriterL<RF_THREADS> EncOut;
+#define RF_RING_BYTES (RF_THREADS * 272)
 
 // v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
 // half-rate instructions); one full-rate add feeding the multiply-add is cheaper
@@ -67,32 +61,14 @@ __device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
     return d;
 }
 
-struct EncSym {
-    u32 bits, k;
-};
-
-// One symbol.  `addr` = 16 * symbol (byte offset into the table).  Table entry {rcp, thresh, c, (M-f) | k1 << 24}
-// with k1 = k0 + 1.  MSH = m - (32 - nsb) + 1 so that  q = mulhi(x, rcp) >> (MSH - [x < thresh]).
-// s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f, s = ceil(log2 f)): the quotient shift
-// s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the pre-shift of x disappears.
+// One symbol.  Table entry {rcp, thresh, c, (M-f) | k1 << 24} with k1 = k0 + 1.  MSH = m - (32 - nsb) + 1 so that
+// q = mulhi(x, rcp) >> (MSH - [x < thresh]).  s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f,
+// s = ceil(log2 f)): the quotient shift s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the
+// pre-shift of x disappears.  The k released bits are never extracted: push() takes the low k bits of x by itself.
 template <int MSH_T>
-__device__ __forceinline__ EncSym rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt) {
+__device__ __forceinline__ void rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt, EncOut &o) {
     // run-time form: msh_rt = MSH | pre << 8.  Tables so small that m < 32 - nsb would need a negative MSH; they
     // shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
-    const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
-    const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
-    const u32 k = (e.w >> 24) - neg;
-    const u32 q = rf_umulhi(MSH_T ? x : (x << (msh_rt >> 8)), e.x) >> (MSH - neg);
-    EncSym r;
-    r.bits = __builtin_amdgcn_ubfe(x, 0, k);
-    r.k = k;
-    x = __umul24(q, e.w) + (x >> k) + e.z;  // v_mad_u32_u24 reads only the low 24 bits of e.w
-    return r;
-}
-
-// window form: the field is never extracted -- push() takes the low k bits of x by itself
-template <int MSH_T>
-__device__ __forceinline__ void rf_encode_entry_w(u32 &x, const uint4 e, u32 msh_rt, AnsBackWriterW<RF_THREADS> &o) {
     const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
     const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
     const u32 k = (e.w >> 24) - neg;
@@ -101,21 +77,9 @@ __device__ __forceinline__ void rf_encode_entry_w(u32 &x, const uint4 e, u32 msh
     x = rf_mad24(q, e.w, (x >> k) + e.z);  // v_mad_u32_u24 reads only the low 24 bits of e.w
 }
 
-template <int MSH_T>
-__device__ __forceinline__ EncSym rf_encode_symbol(u32 &x, u32 addr, const char *tab, u32 msh_rt) {
-    return rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + addr), msh_rt);
-}
-
 struct Entries4 {
     uint4 e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
-#if RF_ABLATE & 1  // timing experiment: no table read (entries made up from the symbol word)
-        e[0] = make_uint4(0x20000000u | w, 0x18000000u, w & 0xFFFu, 16u | (9u << 24));
-        e[1] = make_uint4(0x20000000u | (w >> 3), 0x18000000u, (w >> 8) & 0xFFFu, 16u | (9u << 24));
-        e[2] = make_uint4(0x20000000u | (w >> 5), 0x18000000u, (w >> 16) & 0xFFFu, 16u | (9u << 24));
-        e[3] = make_uint4(0x20000000u | (w >> 7), 0x18000000u, (w >> 20) & 0xFFFu, 16u | (9u << 24));
-        return;
-#endif
         e[0] = *reinterpret_cast<const uint4 *>(tab + ((w << 4) & 0xFF0u));
         e[1] = *reinterpret_cast<const uint4 *>(tab + ((w >> 4) & 0xFF0u));
         e[2] = *reinterpret_cast<const uint4 *>(tab + ((w >> 12) & 0xFF0u));
@@ -123,65 +87,74 @@ struct Entries4 {
     }
 };
 
-// 16 symbols (one 16-byte register) -> 8 merged field pairs.  The table entries of the next four symbols are
-// fetched from LDS while the current four are coded (the state chain is serial, the table reads are not).
+// 16 symbols (one 16-byte register).  The table entries of four symbols are fetched from LDS together (the state
+// chain is serial, the table reads are not).
 // CHECK_SYM: 0 = alphabet of 256 symbols, nothing to check; 1 / 2 = flag bytes above n = K - 1 for n <= 127 /
 // n >= 128 with one SWAR test per four symbols: bit 7 of ((b & 0x7F) + c) says (b & 0x7F) > n (mod 128); OR-ed
 // with b (n <= 127: bytes >= 128 are above n anyway) resp. AND-ed with b (n >= 128: only bytes >= 128 can be).
 // `bad` collects those bits; chk_c = 0x01010101 * (127 - n) resp. 0x01010101 * (255 - n).
+// `pre` holds the entries of the first four symbols on entry and those of `next_w` (the first word of the NEXT block)
+// on exit: the table reads of a word are issued one word ahead of their use, in program order, so that their LDS latency
+// (100+ clocks with the bank conflicts of a random symbol mix) runs under the arithmetic of the current word instead of
+// in front of it -- with two waves per SIMD there is nobody else to hide it.
 template <int CHECK_SYM, int MSH_T>
-__device__ __forceinline__ void rf_encode16(const uint4 v, u32 &x, EncOut &o, u32 &bad, u32 chk_c, char *lds,
-                                            const char *tab, u32 msh_rt) {
-    const u32 wv[4] = {v.x, v.y, v.z, v.w};
+__device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 &pre, u32 &x, EncOut &o, u32 &bad, u32 chk_c,
+                                            char *lds, const char *tab, u32 msh_rt) {
+    const u32 wv[5] = {v.x, v.y, v.z, v.w, next_w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        Entries4 cur;
-        cur.load(wv[d], tab);
+        const Entries4 cur = pre;
+        pre.load(wv[d + 1], tab);
+        asm volatile("" ::: "memory");  // keep the reads here: the compiler would sink them to their first use
         if (CHECK_SYM) {
             const u32 w = wv[d];
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
-#if RF_ENC_WINDOW
-        rf_encode_entry_w<MSH_T>(x, cur.e[0], msh_rt, o);
-        rf_encode_entry_w<MSH_T>(x, cur.e[1], msh_rt, o);
+        rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt, o);
+        rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt, o);
         o.check(lds);
-        rf_encode_entry_w<MSH_T>(x, cur.e[2], msh_rt, o);
-        rf_encode_entry_w<MSH_T>(x, cur.e[3], msh_rt, o);
+        rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt, o);
+        rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt, o);
         o.check(lds);
-#else
-        const EncSym s0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt);
-        const EncSym s1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt);
-        // the later symbol's field goes in front (more significant side) of the earlier one's
-        o.put(lds, (s1.bits << s0.k) | s0.bits, s0.k + s1.k);
-        const EncSym s2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt);
-        const EncSym s3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt);
-        o.put(lds, (s3.bits << s2.k) | s2.bits, s2.k + s3.k);
-#endif
     }
 }
 
 template <int CHECK_SYM, int MSH_T>
-__global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+__global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
                                                                         u64 n_chunks, u8 *__restrict__ out,
                                                                         u64 out_stride, u64 *__restrict__ out_bit_off,
                                                                         u32 *__restrict__ out_nbits,
                                                                         u32 *__restrict__ status) {
-    // one LDS block: [0, 32 KiB) word ring, [32 KiB, 36 KiB) symbol table
-    __shared__ __attribute__((aligned(16))) char s_lds[RF_RING_BYTES + 256 * 16];
-    char *lds = s_lds;
-    const char *tab = s_lds + RF_RING_BYTES;
-    reinterpret_cast<uint4 *>(s_lds + RF_RING_BYTES)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+    // one LDS block: the 4 KiB symbol table first (its offsets then fit the 16-bit offset field of the DS instructions;
+    // behind the rings, at 68 KiB, every table address cost an extra VALU instruction), then 68 KiB of word rings
+    __shared__ __attribute__((aligned(16))) char s_lds[256 * 16 + RF_RING_BYTES];
+    char *lds = s_lds + 256 * 16;
+    const char *tab = s_lds;
+    reinterpret_cast<uint4 *>(s_lds)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
     const u32 msh_rt = P.enc_msh;  // MSH | pre << 8, see rans_fast_build_tables
+    // offsets from the workgroup's first slot (the launch guarantees RF_THREADS * out_stride < 2^32): the store address
+    // is then a uniform base + one 32-bit register, which is also all a helper lane needs to know of its source
+    u8 *wg_out = out + (u64)blockIdx.x * RF_THREADS * out_stride;
     EncOut o;
-    o.init(threadIdx.x, out + (c + 1) * out_stride);
+    o.init(threadIdx.x, (threadIdx.x + 1) * (u32)out_stride);
+    // whole wave, equally long chunks: every lane reaches every flush point, so the quads can store cooperatively
+    const bool coop_out =
+        RF_COOP_STORE && __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
+#define RF_FLUSH()                                 \
+    do {                                           \
+        if (coop_out)                              \
+            o.flush_quad(lds, wg_out, threadIdx.x); \
+        else                                       \
+            o.flush_lane(lds, wg_out);             \
+    } while (0)
     u32 x = P.L;
     u32 bad = 0;
     const u32 chk_c = 0x01010101u * ((CHECK_SYM == 2 ? 255u : 127u) - (P.K - 1));  // unused when K = 256
@@ -190,60 +163,53 @@ __global__ void __launch_bounds__(RF_THREADS, 4) rans_encode_fast_kernel(RansFas
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
     Line128 cur, nxt;
-    if (n_lines) cur.load(src16);
+    Entries4 pre;
+    if (n_lines) {
+        cur.load(src16);
+        pre.load(cur.v[0].x, tab);
+    }
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
         // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
         // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
-        if (!CHECK_SYM)
-            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
-        else if (t + 1 < n_lines)  // the checking variants have no register to spare: this form does not spill
-            nxt.load(src16 + 8 * (t + 1));
-        if (!CHECK_SYM) {
-            // straight-line code for the whole line: an inner loop holding only stores would make the compiler
-            // drain vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
+        nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+        // straight-line code for the whole line: an inner loop holding only stores would make the compiler drain vmcnt
+        // in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, chk_c, lds, tab, msh_rt);
-                if (i & 1) o.maybe_flush(lds);  // every 32 symbols: <= 12 new words on top of <= 15 pending
-            }
-        } else {  // the checking variants fit their registers only as two half-line passes (no spill this way)
-#pragma nounroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], x, o, bad, chk_c, lds, tab, msh_rt);
-                    if (i & 1) o.maybe_flush(lds);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
-            }
+        for (int i = 0; i < 8; ++i) {
+            // (the first word of the next line is only known once the prefetch has landed: its entries are read below)
+            rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], i < 7 ? cur.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
+            // every 64 symbols (<= 26 new words on top of <= 31 pending, ring of 64) -- after the symbols 32 and 96 of the
+            // line, NOT 64 and 128: the wait for the prefetched line at the end of the iteration is an s_waitcnt vmcnt(0)
+            // (loads and stores share one in-order counter and the stores sit in conditional code, so the compiler cannot
+            // count them), i.e. it also waits for every store issued so far to COMPLETE; stores issued just before it
+            // cost their whole round trip
+            if ((i & 3) == RF_FLUSH_PHASE) RF_FLUSH();
         }
         cur = nxt;
+        pre.load(cur.v[0].x, tab);
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
-        rf_encode16<CHECK_SYM, MSH_T>(*reinterpret_cast<const uint4 *>(src + i), x, o, bad, chk_c, lds, tab, msh_rt);
-        o.maybe_flush(lds);
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+        pre.load(v.x, tab);
+        rf_encode16<CHECK_SYM, MSH_T>(v, 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
+        RF_FLUSH();
     }
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
-#if RF_ENC_WINDOW
-        rf_encode_entry_w<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o);
+        rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o);
         o.check(lds);
-#else
-        const EncSym s = rf_encode_symbol<MSH_T>(x, a, tab, msh_rt);
-        o.put(lds, s.bits, s.k);
-#endif
-        if ((i & 15u) == 15u) o.maybe_flush(lds);
+        if ((i & 15u) == 15u) RF_FLUSH();
     }
-    o.maybe_flush(lds);
+    RF_FLUSH();
+#undef RF_FLUSH
     o.put32(lds, x, P.nsb);
     u32 st = (CHECK_SYM && (bad & 0x80808080u)) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
     o.put32(lds, n, P.size_bits);
-    const u64 total = o.finish(lds);
+    const u64 total = o.finish(lds, wg_out);
     out_bit_off[c] = (c + 1) * out_stride * 8 - total;
     out_nbits[c] = (u32)total;
     if (status) status[c] = st;

@@ -351,7 +351,8 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
         return SCL_OK;
     }
     if (m->rans && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
-        out_stride >= scl_rans_slot_bytes(m->rans, chunk_len)) {  // same stream from the table-free rANS kernels
+        out_stride >= scl_rans_slot_bytes(m->rans, chunk_len) &&
+        out_stride < (1ull << 24)) {  // same stream from the table-free rANS kernels (32-bit slot offsets per workgroup)
         rans_fast_encode_launch(m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                 d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());

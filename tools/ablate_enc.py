@@ -16,13 +16,14 @@ if PAD:
     sym = padded[:, :chunk_len]
 enc = model.alloc_encoded(n_chunks, chunk_len, dev, out_stride=int(os.environ.get('SLOT', 0)) or None)
 dec = model.alloc_decoded(n_chunks, chunk_len + PAD, dev)
-for _ in range(2):
+for _ in range(int(os.environ.get('WARM', 20))):
     model.encode_batch(sym, out=enc); model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec)
 torch.cuda.synchronize()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 te = td = 0
-for _ in range(5):
+REPS = int(os.environ.get('REPS', 30))
+for _ in range(REPS):
     e[0].record(); model.encode_batch(sym, out=enc); e[1].record()
     model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
     torch.cuda.synchronize(); te += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
-print(f"{os.environ.get('ABL','base')} chunks={n_chunks} pad={PAD} slot={enc.stride}: encode {te/5:.3f} ms  decode {td/5:.3f} ms")
+print(f"{os.environ.get('ABL','base')} chunks={n_chunks} pad={PAD} slot={enc.stride}: encode {te/REPS:.3f} ms  decode {td/REPS:.3f} ms")

@@ -1,0 +1,97 @@
+// linecopy3.hip -- mixed read + write of the lane-per-chunk line pattern with different request shapes, no arithmetic:
+// each wave owns 64 chunks (4 KiB in, 29 lines of 128 B out into 6272-byte slots), one input line per step.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef uint32_t u32; typedef uint64_t u64;
+#define CHUNK 4096
+#define SLOT 6272
+// RD: 0 per-lane (8 x 16 B of the lane's own line), 1 cooperative (8 lanes per line)
+// WR: 0 per-lane whole line (8 x 16 B), 1 cooperative whole line (8 lanes per line), 2 quad half lines (4 lanes x 16 B, two
+//     per line at different steps), 3 per-lane half lines
+template <int RD, int WR, int PACE = 0>
+__global__ void __launch_bounds__(256, 4) mixed(const uint4 *__restrict__ in, uint4 *__restrict__ out, u64 n_chunks, u32 *sink) {
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 c0 = c - lane;
+    uint4 acc = make_uint4(1, 2, 3, 4);
+    u32 frac = 0, wl = 0;
+    for (u32 j = 0; j < CHUNK / 128; ++j) {
+        uint4 v[8];
+        if (RD == 2) {
+            for (int i = 0; i < 8; ++i) v[i] = make_uint4(j, i, acc.x, acc.y);
+        } else if (RD == 0) {
+            for (int i = 0; i < 8; ++i) v[i] = in[c * (CHUNK / 16) + j * 8 + i];
+        } else {
+            for (int i = 0; i < 8; ++i) v[i] = in[(c0 + (lane & 7u) + 8 * i) * (CHUNK / 16) + j * 8 + (lane >> 3)];
+        }
+        for (int i = 0; i < 8; ++i) { acc.x ^= v[i].x; acc.y += v[i].y; acc.z ^= v[i].z; acc.w += v[i].w; }
+        if (PACE) {  // PACE dependent multiply-adds per line: stands for the coder's arithmetic
+            u32 x = acc.x;
+#pragma unroll 8
+            for (int p = 0; p < PACE; ++p) x = x * 2654435761u + (x >> 7);
+            acc.x = x;
+        }
+        frac += 233;
+        const bool w = WR != 9 && frac >= 256 && wl < 29;   // same for all lanes here (uniform rate)
+        if (w) {
+            frac -= 256;
+            ++wl;
+            if (WR == 0) {
+                uint4 *p = out + (c + 1) * (SLOT / 16) - wl * 8;
+                for (int i = 0; i < 8; ++i) p[i] = make_uint4(acc.x + i, acc.y, acc.z, v[i].x);
+            } else if (WR == 1) {
+                for (int i = 0; i < 8; ++i)
+                    out[(c0 + (lane & 7u) + 8 * i + 1) * (SLOT / 16) - wl * 8 + (lane >> 3)] = make_uint4(acc.x + i, acc.y, acc.z, v[i].x);
+            } else if (WR == 2) {
+                // two half lines, 4 rounds each: round r = chunk 4Q + r of the quad, lane j = piece j
+                for (int h = 0; h < 2; ++h)
+                    for (int r = 0; r < 4; ++r)
+                        out[((c & ~3ull) + r + 1) * (SLOT / 16) - wl * 8 + h * 4 + (lane & 3u)] = make_uint4(acc.x + r, acc.y, h, v[r].x);
+            } else {
+                uint4 *p = out + (c + 1) * (SLOT / 16) - wl * 8;
+                for (int i = 0; i < 4; ++i) p[i + 4] = make_uint4(acc.x + i, acc.y, acc.z, v[i].x);
+            }
+        }
+        if (WR == 3 && (j & 1) && wl) {  // the other half, a step later
+            uint4 *p = out + (c + 1) * (SLOT / 16) - wl * 8;
+            for (int i = 0; i < 4; ++i) p[i] = make_uint4(acc.x + i, acc.y, acc.z, v[i].x);
+        }
+    }
+    if (acc.x == 0x12345678 && acc.y == 0x9abcdef0) sink[0] = acc.z + acc.w;
+}
+template <typename F> static float time_ms(F f, int reps = 10) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    f(); f(); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+int main() {
+    const u64 n_chunks = 262144;
+    uint4 *in, *out; u32 *sink;
+    (void)hipMalloc(&in, n_chunks * CHUNK); (void)hipMalloc(&out, n_chunks * SLOT + 65536); (void)hipMalloc(&sink, 64);
+    (void)hipMemset(in, 1, n_chunks * CHUNK);
+    const double bytes = (double)n_chunks * (CHUNK + 29 * 128);
+#define T(NAME, RD, WR) { float ms = time_ms([&] { hipLaunchKernelGGL((mixed<RD, WR>), dim3(n_chunks / 256), dim3(256), 0, 0, in, out, n_chunks, sink); }); \
+        printf("%-60s : %.3f ms  %.2f TB/s\n", NAME, ms, bytes / ms / 1e9); }
+    T("read per-lane, write per-lane whole lines", 0, 0)
+    T("read per-lane, write per-lane half lines", 0, 3)
+    T("read per-lane, write quad half lines", 0, 2)
+    T("read per-lane, write cooperative whole lines", 0, 1)
+    T("read cooperative, write per-lane whole lines", 1, 0)
+    T("read cooperative, write quad half lines", 1, 2)
+    T("read cooperative, write cooperative whole lines", 1, 1)
+#define TP(NAME, RD, WR, PACE) { float ms = time_ms([&] { hipLaunchKernelGGL((mixed<RD, WR, PACE>), dim3(n_chunks / 256), dim3(256), 0, 0, in, out, n_chunks, sink); }); \
+        printf("%-52s pace %4d : %.3f ms  %.2f TB/s\n", NAME, PACE, ms, bytes / ms / 1e9); }
+    TP("no memory traffic at all (compute only)", 2, 9, 400)
+    TP("no memory traffic at all (compute only)", 2, 9, 600)
+    TP("read per-lane, write per-lane whole lines", 0, 0, 400)
+    TP("read per-lane, write per-lane whole lines", 0, 0, 600)
+    TP("read per-lane, write cooperative whole lines", 0, 1, 400)
+    TP("read per-lane, write cooperative whole lines", 0, 1, 600)
+    TP("read cooperative, write cooperative whole lines", 1, 1, 400)
+    TP("read cooperative, write cooperative whole lines", 1, 1, 600)
+    TP("read per-lane, no writes", 0, 9, 400)
+    TP("read per-lane, no writes", 0, 9, 600)
+    return 0;
+}
