@@ -252,6 +252,27 @@ int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const
                         uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
                         uint64_t *d_out_byte_offset, void *d_scratch, void *stream);
 
+/* ---- multi-GPU: variable-length gather of compacted streams over RCCL (SURVEY.md 8e, configs[4]) ------
+ * No reference counterpart (the reference has no communication).  One process per GPU; every rank encodes and
+ * compacts its own block-contiguous shard, then the dense payloads go to one rank: an all-gather of the byte
+ * counts, then one grouped ncclSend / ncclRecv per sender straight into the root's buffer at the prefix offsets
+ * (xGMI is point to point: the root receives on all its links at once).  RCCL is dlopen'ed on first use.
+ *   scl_rccl_unique_id      : rank 0 creates the 128-byte id and hands it to the others out of band (any channel);
+ *   scl_rccl_comm_create    : collective over the `world` ranks; the communicator belongs to the current device;
+ *   scl_rccl_allgather_u64  : collective; one u64 per rank -> h_out[world] on every rank (synchronises `stream`):
+ *                             the byte counts, so that the root can size its buffer before anything is posted;
+ *   scl_streams_gather_rccl : collective, asynchronous on `stream`: rank r's send_bytes bytes arrive at the root's
+ *                             d_recv + h_rank_offsets[r]; h_rank_offsets[world + 1] (host) = exclusive prefix sum
+ *                             of the counts, last entry = total.  d_recv matters on the root only.  Call it again
+ *                             to move the per-chunk offset tables. */
+typedef struct scl_comm scl_comm;
+int scl_rccl_unique_id(uint8_t *id128);
+int scl_rccl_comm_create(const uint8_t *id128, int rank, int world, scl_comm **out);
+void scl_rccl_comm_destroy(scl_comm *c);
+int scl_rccl_allgather_u64(scl_comm *c, uint64_t value, uint64_t *h_out, void *stream);
+int scl_streams_gather_rccl(scl_comm *c, int root, const uint8_t *d_send, uint64_t send_bytes, uint8_t *d_recv,
+                            const uint64_t *h_rank_offsets, void *stream);
+
 /* ---- model construction helper (row f3): symbol histogram ------------------------------------------ */
 /* d_counts[256] (uint64) += number of occurrences of every byte value in d_sym[0..n).  The caller zeroes
    d_counts.  Equals DataBlock.get_counts() (scl/core/data_block.py:37-62) for uint8 data. */

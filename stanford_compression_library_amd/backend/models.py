@@ -362,6 +362,32 @@ class AecModel(_DeviceModel):
         return sym[:, :chunk_cap], lens, used, status
 
 
+def compact_into(enc: EncodedBatch, out, offsets, scratch, framed: bool = False, stream=None):
+    """Asynchronous form of :func:`compact`: the dense (or framed) concatenation of ``enc`` goes into caller-owned
+    device buffers -- ``out`` uint8 (capacity >= every record: ``compact_capacity``), ``offsets`` int64 [n + 1],
+    ``scratch`` uint8 [``scl_streams_compact_scratch_bytes(n)``] -- on ``stream`` (a torch stream; default: current).
+    Nothing synchronises; ``offsets[-1]`` is the total once the stream has got there."""
+    import torch
+
+    L = _lib.load()
+    dev = enc.data.device
+    st = stream if stream is not None else torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), enc.n_chunks,
+                                   _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), out.numel(),
+                                   offsets.data_ptr(), scratch.data_ptr(), st.cuda_stream)
+    _lib.check(rc, "scl_streams_compact")
+
+
+def compact_capacity(n_chunks: int, stride: int, framed: bool = False) -> int:
+    """bytes that always hold the compaction of ``n_chunks`` slots of ``stride`` bytes"""
+    return int(n_chunks) * (int(stride) + (6 if framed else 1)) + 16
+
+
+def compact_scratch_bytes(n_chunks: int) -> int:
+    return int(_lib.load().scl_streams_compact_scratch_bytes(int(n_chunks)))
+
+
 def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     """Dense (or EncodedBlockWriter-framed) concatenation of a batch: -> (bytes tensor, int64 offsets[n+1])."""
     import torch

@@ -4,15 +4,23 @@ Chunks share nothing but read-only model tables, so the path shards embarrassing
 (SURVEY.md section 8e): rank r owns a block-contiguous range of chunks, runs the same single-GPU
 kernels on it, and no collective sits on the data path.  The only exchange step is the optional final
 *variable-length gather* of the compacted per-chunk streams to one rank (BASELINE.json configs[4]):
-an all_gather of byte counts followed by direct point-to-point transfers into the root's buffer at the
-prefix offsets -- over RCCL each sender uses its own xGMI link to the root, so no ring is involved.
+the byte counts travel first, then every sender's payload goes straight into the root's buffer at the prefix
+offsets -- over RCCL each sender uses its own xGMI link to the root, so no ring is involved.
 
-Everything here is backend-agnostic ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" in the
-CPU tests).
+Two transports, same result:
+* ``RcclGather`` -- the C ABI's ``scl_rccl_*`` / ``scl_streams_gather_rccl`` (csrc/scl_gather.hip: grouped
+  ncclSend / ncclRecv on a HIP stream of our choice, which is what lets a gather overlap the next encode);
+  used when the process group runs on RCCL ("nccl" backend);
+* plain ``torch.distributed`` point-to-point ops -- any backend, "gloo" in the CPU tests.
+``encode_gather_overlapped`` is configs[4] end to end: the rank's shard is cut into sub-batches, and sub-batch i
+travels on the communication stream while sub-batch i + 1 is encoded and compacted on the compute stream.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
+
+import numpy as np
 
 
 def shard_range(n_units: int, world: int, rank: int) -> Tuple[int, int]:
@@ -23,14 +31,108 @@ def shard_range(n_units: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def block_offsets(chunk_offsets, chunks_per_block: int):
+    """Byte offset of every block of ``chunks_per_block`` chunks (configs[4]: 1 MiB blocks = 256 chunks of 4 KiB)
+    from the per-chunk offsets ``scl_streams_compact`` returns (n + 1 entries); the last entry stays the total."""
+    n = int(chunk_offsets.numel()) - 1
+    idx = list(range(0, n, int(chunks_per_block))) + [n]
+    return chunk_offsets[idx]
+
+
+class RcclGather:
+    """Communicator of ``scl_rccl_*`` over the ranks of the default ``torch.distributed`` group.  The 128-byte id is
+    created on rank 0 and handed out through the group (any backend); the communicator belongs to ``device``."""
+
+    def __init__(self, world: int, rank: int, device):
+        import torch
+        import torch.distributed as dist
+
+        from . import lib as _lib
+
+        self._L = _lib.load()
+        self.world, self.rank, self.device = int(world), int(rank), device
+        ident = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            _lib.check(self._L.scl_rccl_unique_id(_lib.u8_ptr(ident)), "scl_rccl_unique_id")
+        if world > 1:
+            box = [ident.tobytes() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ident = np.frombuffer(box[0], dtype=np.uint8).copy()
+        self._h = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = self._L.scl_rccl_comm_create(_lib.u8_ptr(ident), self.rank, self.world, C.byref(self._h))
+        _lib.check(rc, "scl_rccl_comm_create")
+        self._check = _lib.check
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.scl_rccl_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sizes(self, nbytes: int, stream=None) -> np.ndarray:
+        """all ranks' byte counts as exclusive prefix offsets [world + 1] (collective; synchronises the stream)"""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        counts = np.zeros(self.world, dtype=np.uint64)
+        with torch.cuda.device(self.device):
+            rc = self._L.scl_rccl_allgather_u64(self._h, int(nbytes), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                st.cuda_stream)
+        self._check(rc, "scl_rccl_allgather_u64")
+        return np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+
+    def gather(self, payload, nbytes: int, offsets: np.ndarray, out=None, root: int = 0, stream=None):
+        """asynchronous on ``stream``: this rank's ``payload[:nbytes]`` (uint8, device) -> ``out[offsets[rank]:]`` on the root"""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        with torch.cuda.device(self.device):
+            rc = self._L.scl_streams_gather_rccl(self._h, int(root), payload.data_ptr() if nbytes else None, int(nbytes),
+                                                 out.data_ptr() if out is not None else None,
+                                                 offs.ctypes.data_as(C.POINTER(C.c_uint64)), st.cuda_stream)
+        self._check(rc, "scl_streams_gather_rccl")
+
+
+def _gather_torch(payload, nbytes, world, rank, device, dst, counts):
+    """torch.distributed transport of one variable-length gather; returns the root's buffer (None elsewhere)"""
+    import torch
+    import torch.distributed as dist
+
+    base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    out = None
+    if rank == dst:
+        out = torch.empty(int(base[-1]), dtype=payload.dtype, device=device)
+        ops = []
+        for r in range(world):
+            if r == dst:
+                out[base[r]:base[r + 1]] = payload[:nbytes]
+            elif counts[r]:
+                ops.append(dist.P2POp(dist.irecv, out[base[r]:base[r + 1]], r))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    elif nbytes:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload[:nbytes].contiguous(), dst)]):
+            req.wait()
+    return out
+
+
 def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, dst: int = 0,
-                           return_data: bool = False):
+                           return_data: bool = False, comm: Optional[RcclGather] = None):
     """Gather every rank's compacted stream buffer (``dense[:offsets[-1]]``) and per-chunk byte offsets to
     ``dst``.
 
     Returns the total gathered byte count on every rank; with ``return_data`` the root additionally gets
     ``(bytes_tensor, global_offsets)`` where ``global_offsets`` has one entry per chunk of every rank (rank
     order) plus the grand total, i.e. exactly what a single process would have produced.
+    ``comm``: an :class:`RcclGather` -- the transfers then run through the C ABI on the current HIP stream.
     """
     import torch
     import torch.distributed as dist
@@ -38,44 +140,103 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
     device = device if device is not None else dense.device
     n_local = int(offsets.numel()) - 1
     my_bytes = int(offsets[-1].item())
-    meta = torch.tensor([my_bytes, n_local], dtype=torch.int64, device=device)
-    all_meta = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_meta, meta)
-    sizes = [int(m[0].item()) for m in all_meta]
-    counts = [int(m[1].item()) for m in all_meta]
-    total = sum(sizes)
-    byte_base = [sum(sizes[:r]) for r in range(world)]
-    out = goffs = None
-    if rank == dst:
-        out = torch.empty(total, dtype=torch.uint8, device=device)
-        goffs = torch.empty(sum(counts) + 1, dtype=torch.int64, device=device)
-        ops, pos = [], 0
-        for r in range(world):
-            if r == dst:
-                out[byte_base[r]:byte_base[r] + sizes[r]] = dense[:sizes[r]]
-                goffs[pos:pos + counts[r]] = offsets[:counts[r]] + byte_base[r]
-            else:
-                if sizes[r]:
-                    ops.append(dist.P2POp(dist.irecv, out[byte_base[r]:byte_base[r] + sizes[r]], r))
-                ops.append(dist.P2POp(dist.irecv, goffs[pos:pos + counts[r]], r))
-            pos += counts[r]
-        goffs[-1] = total
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        # offsets of remote ranks arrive relative to their own buffers
-        pos = 0
-        for r in range(world):
-            if r != dst:
-                goffs[pos:pos + counts[r]] += byte_base[r]
-            pos += counts[r]
+    if comm is not None:
+        base = comm.sizes(my_bytes).astype(np.int64)
+        cbase = comm.sizes(8 * n_local).astype(np.int64) // 8
+        sizes, counts = np.diff(base), np.diff(cbase)
     else:
-        ops = []
-        if my_bytes:
-            ops.append(dist.P2POp(dist.isend, dense[:my_bytes].contiguous(), dst))
-        ops.append(dist.P2POp(dist.isend, offsets[:n_local].contiguous(), dst))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        meta = torch.tensor([my_bytes, n_local], dtype=torch.int64, device=device)
+        all_meta = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(all_meta, meta)
+        sizes = np.array([int(m[0].item()) for m in all_meta], dtype=np.int64)
+        counts = np.array([int(m[1].item()) for m in all_meta], dtype=np.int64)
+        base = np.concatenate([[0], np.cumsum(sizes)])
+        cbase = np.concatenate([[0], np.cumsum(counts)])
+    total = int(base[-1])
+    out = goffs = None
+    local_offs = offsets[:n_local].contiguous()
+    if comm is not None:
+        if rank == dst:
+            out = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+            goffs = torch.empty(int(cbase[-1]) + 1, dtype=torch.int64, device=device)
+        comm.gather(dense, my_bytes, base.astype(np.uint64), out, root=dst)
+        comm.gather(local_offs.view(torch.uint8), 8 * n_local, (8 * cbase).astype(np.uint64),
+                    goffs.view(torch.uint8) if goffs is not None else None, root=dst)
+        torch.cuda.current_stream(device).synchronize()
+        if out is not None:
+            out = out[:total]
+    else:
+        out = _gather_torch(dense, my_bytes, world, rank, device, dst, sizes)
+        g = _gather_torch(local_offs, n_local, world, rank, device, dst, counts)
+        if rank == dst:
+            goffs = torch.empty(int(cbase[-1]) + 1, dtype=torch.int64, device=device)
+            goffs[:-1] = g
+    if rank == dst:
+        # offsets arrive relative to their own rank's buffer
+        for r in range(world):
+            goffs[cbase[r]:cbase[r + 1]] += int(base[r])
+        goffs[-1] = total
     if return_data:
         return total, out, goffs
     return total
+
+
+def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: int = 8, dst: int = 0,
+                             comm: Optional[RcclGather] = None, framed: bool = False):
+    """configs[4] end to end for this rank's shard ``sym`` (uint8 [n_chunks, chunk_len] on the device): the shard is
+    cut into ``n_sub`` sub-batches; each is encoded and compacted on the compute stream (nothing there waits for the
+    host), and its dense payload + per-chunk offsets are gathered to ``dst`` on a second stream while the NEXT
+    sub-batch is already running: the host enqueues sub-batch i + 1 before it waits for sub-batch i's byte count.
+
+    Returns (timings dict, on the root a list of per-sub-batch (bytes, global_offsets) pairs in sub-batch order -- the
+    root's buffer for sub-batch i holds the ranks' sub-batch-i payloads in rank order --, None elsewhere).
+    """
+    import time
+
+    import torch
+
+    from .models import compact_capacity, compact_into, compact_scratch_bytes
+
+    dev = sym.device
+    n_chunks, chunk_len = sym.shape
+    bounds = [n_chunks * i // n_sub for i in range(n_sub + 1)]
+    comp, comm_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    comp.wait_stream(torch.cuda.current_stream(dev))
+    stride = model.slot_bytes(chunk_len)
+    jobs, results = [], []
+    t0 = time.perf_counter()
+
+    def enqueue(i):
+        a, b = bounds[i], bounds[i + 1]
+        with torch.cuda.stream(comp):
+            enc = model.encode_batch(sym[a:b], stream=comp.cuda_stream, out_stride=stride)
+            dense = torch.empty(compact_capacity(b - a, stride, framed), dtype=torch.uint8, device=dev)
+            offs = torch.empty(b - a + 1, dtype=torch.int64, device=dev)
+            scratch = torch.empty(compact_scratch_bytes(b - a), dtype=torch.uint8, device=dev)
+            compact_into(enc, dense, offs, scratch, framed=framed, stream=comp)
+            total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            total.copy_(offs[-1:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(comp)
+        return dict(enc=enc, dense=dense, offs=offs, scratch=scratch, total=total, ev=ev)
+
+    def send(job):
+        job["ev"].synchronize()  # this sub-batch only: later ones keep running
+        comm_stream.wait_event(job["ev"])
+        with torch.cuda.stream(comm_stream):
+            if world > 1 or comm is not None:
+                return gather_streams_to_root(job["dense"], job["offs"], world, rank, dev, dst, return_data=True, comm=comm)
+            n = int(job["total"][0])
+            return n, job["dense"][:n], job["offs"]
+
+    for i in range(n_sub + 1):
+        if i < n_sub:
+            jobs.append(enqueue(i))
+        if i >= 1:
+            results.append(send(jobs[i - 1]))
+    comm_stream.synchronize()
+    comp.synchronize()
+    total_ms = (time.perf_counter() - t0) * 1e3
+    timings = {"overlapped_ms": round(total_ms, 3), "sub_batches": n_sub,
+               "gathered_bytes": int(sum(r[0] for r in results))}
+    return timings, ([(r[1], r[2]) for r in results] if rank == dst else None)

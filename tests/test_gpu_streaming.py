@@ -110,7 +110,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, SCL_BENCH_SHARED_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--chunks", "4096", "--no-cpu-baseline"]
+           "--chunks", "4096", "--no-cpu-baseline", "--gather"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -118,6 +118,10 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
     assert out["value"] > 0 and out["config"]["chunks_per_gpu"] == 4096
+    assert out["value_definition"] == "slots" and 0 < out["value_dense"] < out["value"]
+    g = out["gather"]  # configs[4]: encode -> compact -> gather, sequential and as a pipeline of sub-batches
+    assert g["gathered_bytes"] > 2 * 4096 * 3000 and g["blocks_1MiB"] == 2 * 4096 // 256
+    assert all(g[k] > 0 for k in ("encode_ms", "compact_ms", "gather_ms", "sequential_ms", "overlapped_ms"))
 
 
 def test_stream_driver_custom_writer_and_bounded_batches(tmp_path, monkeypatch):
