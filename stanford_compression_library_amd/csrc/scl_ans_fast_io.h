@@ -165,13 +165,15 @@ struct AnsBackWriter {
 //     v_alignbit takes the low k bits of its first operand by itself: no field extraction (v_bfe), no merging of two
 //     fields, no shift of the field to its place in an accumulator.  check() every two symbols (n <= 32 + 2*13 < 64):
 //     n >= 33 means the oldest 32 bits, alignbit(hi, lo, 64 - n), are a complete word; the rest of the window stays
-//     where it is (top-aligned), n -= 32.  n is kept negated (nn = -n) so that the word's shift amount is nn itself
-//     (v_alignbit reads the low 5 bits: (-n) mod 32 = 64 - n for 33 <= n <= 63).
-// (2) Ring.  256 bytes per lane, [thread][word] with a 272-byte thread stride: the two halves are two 128-byte line
-//     buffers holding words in MEMORY order (the stream grows downwards, so the write offset walks 124, 120, .. 0, 252,
-//     .. 128, 124, ..: (wl - 4) & 252).  A lane's scattered 4-byte writes now collide in the banks now and then
-//     (bank = (4 t + w) mod 32), which ds_write_b32 mostly hides; what the layout buys is that a 16-byte piece of a line
-//     is ONE aligned ds_read_b128 -- for any lane.
+//     where it is (top-aligned), n -= 32.  The counter is room = 32 - n, unsigned: the subtraction that accounts for a
+//     pair of symbols borrows exactly when n reaches 33 (no compare instruction), and the wrapped value's low 5 bits are
+//     the word's shift amount (v_alignbit reads 5 bits: (32 - n) mod 32 = 64 - n for 33 <= n <= 63).
+// (2) Ring.  256 bytes per lane, [thread][word]: the two halves are two 128-byte line buffers holding words in MEMORY
+//     order (the stream grows downwards, so the write offset walks 124, 120, .. 0, 252, .. 128, 124, ..).  The ring is
+//     256-byte aligned, so the write ADDRESS is the only state: wa = ((wa - 4) & 255) | base.  A lane's scattered 4-byte
+//     writes now collide in the banks (bank = word index mod 32, whatever the lane), which ds_write_b32 mostly hides
+//     (measured: no slower than the conflict-free [word][thread] layout of round 1); what the layout buys is that a
+//     16-byte piece of a line is ONE aligned ds_read_b128 -- for any lane.
 // (3) Stores.  What bounds a lane-per-chunk coder on this chip is the SHAPE of its write requests: with the same
 //     lines, the same bytes and no arithmetic at all, lanes storing their own lines (8 x 16 bytes) take 0.58 ms per GiB
 //     batch, four lanes per 64-byte half line 0.52, eight lanes per whole line 0.42 (tools/ubench/linecopy3.hip; the read
@@ -190,49 +192,52 @@ __device__ __forceinline__ u32 scl_quad_bcast(u32 v) {  // value of lane R of th
 }
 template <int THREADS>
 struct AnsBackWriterL {
-    static constexpr u32 LANE_BYTES = 272;                   // 256-byte ring + 16 bytes of skew
+    static constexpr u32 LANE_BYTES = 256;                   // one 256-byte ring per lane, 256-byte aligned
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup
     u32 hi, lo;   // the window
-    int nn;       // minus the number of pending bits
-    u32 wl;       // ring offset (bytes, 0..252) of the word that completes next
+    u32 room;     // 32 - (number of pending bits), as an unsigned counter: a push that BORROWS completed a word
+    u32 wa;       // LDS byte address (from the ring base) of the word that completes next: base | offset 0..252
     u32 th4;      // 124 or 252: offset of the FIRST word of the oldest unflushed line (top of its half)
-    u32 base;     // tid * LANE_BYTES
+    u32 base;     // tid * LANE_BYTES (low 8 bits zero)
     u32 goff;     // byte offset (from the workgroup's output base) of the END of the next line to store
     u32 goff0;    // ... of the slot end
 
-    __device__ __forceinline__ u32 pend4() const { return (th4 - wl) & 255u; }  // 4 * completed words not yet stored (< 256)
+    __device__ __forceinline__ u32 pend4() const { return (th4 - wa) & 255u; }  // 4 * completed words not yet stored (< 256)
 
     __device__ __forceinline__ void init(u32 tid, u32 slot_end_off) {
         hi = lo = 0;
-        nn = 0;
-        wl = 124;
-        th4 = 124;
+        room = 32;
         base = tid * LANE_BYTES;
+        wa = base | 124u;
+        th4 = 124;
         goff = goff0 = slot_end_off;
     }
     // the low k bits of v go in front of the stream; k < 32, bits of v above bit k are ignored
     __device__ __forceinline__ void push(u32 v, u32 k) {
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
         hi = __builtin_amdgcn_alignbit(v, hi, k);
-        nn -= (int)k;
     }
-    __device__ __forceinline__ void check(char *lds) {  // after at most 26 pushed bits
-        if (nn < -32) {
-            const u32 word = __builtin_amdgcn_alignbit(hi, lo, (u32)nn);
-            *reinterpret_cast<u32 *>(lds + base + wl) = __builtin_bswap32(word);
-            wl = (wl - 4u) & 252u;
-            nn += 32;
+    // account for the `bits` (<= 26) pushed since the last call.  The subtraction's borrow IS the test "33 or more bits
+    // pending" (v_sub_co_u32 + a branch on VCC: no separate compare); the wrapped counter's low 5 bits are the shift that
+    // brings the oldest 32 bits down: (32 - n) mod 32 = 64 - n for 33 <= n <= 63.
+    __device__ __forceinline__ void check(char *lds, u32 bits) {
+        if (__builtin_usub_overflow(room, bits, &room)) {
+            const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
+            *reinterpret_cast<u32 *>(lds + wa) = __builtin_bswap32(word);
+            wa = ((wa - 4u) & 255u) | base;  // one v_add + one v_and_or: the address register is the only state
+            room += 32;
         }
     }
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
         if (w > 16) {
             push(v, 16);
-            check(lds);
+            check(lds, 16);
             push(v >> 16, w - 16);
+            check(lds, w - 16);
         } else {
             push(v, w);
+            check(lds, w);
         }
-        check(lds);
     }
     template <int R>
     __device__ __forceinline__ void quad_round(const char *lds, u8 *wg_out, u32 f, u32 qj, u32 j16) const {
@@ -286,7 +291,7 @@ struct AnsBackWriterL {
             end32[-(i64)j - 1] = *reinterpret_cast<const u32 *>(lds + base + a);
             a = (a - 4u) & 252u;
         }
-        const u32 n = (u32)(-nn);  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
+        const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
         if (n) end32[-(i64)np - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
         return (u64)(((goff0 - goff) >> 2) + np) * 32 + n;
     }

@@ -49,9 +49,9 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 //           lanes per line + an 8 x 8 register transpose, was built and measured: 3 % slower -- the read shape is not what
 //           bounds the kernel, tools/ubench/linecopy3.hip.)
 //   output: AnsBackWriterL (scl_ans_fast_io.h): bit window -> 64-word LDS ring per lane -> whole lines stored by quads.
-// LDS per workgroup: 68 KiB ring + 4 KiB table = two workgroups per CU (2 waves per SIMD; 4 measured the same).
+// LDS per workgroup: 64 KiB ring + 4 KiB table = two workgroups per CU (2 waves per SIMD; 4 measured the same).
 typedef AnsBackWriterL<RF_THREADS> EncOut;
-#define RF_RING_BYTES (RF_THREADS * 272)
+#define RF_RING_BYTES (RF_THREADS * 256)
 
 // v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
 // half-rate instructions); one full-rate add feeding the multiply-add is cheaper
@@ -66,7 +66,7 @@ __device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
 // s = ceil(log2 f)): the quotient shift s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the
 // pre-shift of x disappears.  The k released bits are never extracted: push() takes the low k bits of x by itself.
 template <int MSH_T>
-__device__ __forceinline__ void rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt, EncOut &o) {
+__device__ __forceinline__ u32 rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt, EncOut &o) {  // returns k
     // run-time form: msh_rt = MSH | pre << 8.  Tables so small that m < 32 - nsb would need a negative MSH; they
     // shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
     const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
@@ -75,6 +75,7 @@ __device__ __forceinline__ void rf_encode_entry(u32 &x, const uint4 e, u32 msh_r
     const u32 q = rf_umulhi(MSH_T ? x : (x << (msh_rt >> 8)), e.x) >> (MSH - neg);
     o.push(x, k);
     x = rf_mad24(q, e.w, (x >> k) + e.z);  // v_mad_u32_u24 reads only the low 24 bits of e.w
+    return k;
 }
 
 struct Entries4 {
@@ -111,12 +112,12 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
-        rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt, o);
-        rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt, o);
-        o.check(lds);
-        rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt, o);
-        rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt, o);
-        o.check(lds);
+        const u32 k0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt, o);
+        const u32 k1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt, o);
+        o.check(lds, k0 + k1);
+        const u32 k2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt, o);
+        const u32 k3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt, o);
+        o.check(lds, k2 + k3);
     }
 }
 
@@ -129,11 +130,18 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
                                                                         u32 *__restrict__ out_nbits,
                                                                         u32 *__restrict__ status) {
     // one LDS block: the 4 KiB symbol table first (its offsets then fit the 16-bit offset field of the DS instructions;
-    // behind the rings, at 68 KiB, every table address cost an extra VALU instruction), then 68 KiB of word rings
-    __shared__ __attribute__((aligned(16))) char s_lds[256 * 16 + RF_RING_BYTES];
-    char *lds = s_lds + 256 * 16;
-    const char *tab = s_lds;
-    reinterpret_cast<uint4 *>(s_lds)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+    // behind the rings, every table address cost an extra VALU instruction), then 64 KiB of word rings
+#ifndef RF_TAB_COPIES
+#define RF_TAB_COPIES 1
+#endif
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + RF_RING_BYTES];
+    char *lds = s_lds + RF_TAB_COPIES * 256 * 16;
+    // RF_TAB_COPIES = 2 (experiment): odd lanes read a second copy of the table -- the 16 lanes of a ds_read_b128 pass
+    // then spread over twice the banks
+    const char *tab = s_lds + (RF_TAB_COPIES == 2 ? (threadIdx.x & 1u) * 4096u : 0u);
+#pragma unroll
+    for (int cpy = 0; cpy < RF_TAB_COPIES; ++cpy)
+        reinterpret_cast<uint4 *>(s_lds + cpy * 4096)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -199,8 +207,7 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
-        rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o);
-        o.check(lds);
+        o.check(lds, rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o));
         if ((i & 15u) == 15u) RF_FLUSH();
     }
     RF_FLUSH();

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256, 4) mixed(const uint4 *__restrict__ in, ui
     const u32 lane = threadIdx.x & 63u;
     const u64 c0 = c - lane;
     uint4 acc = make_uint4(1, 2, 3, 4);
-    u32 frac = 0, wl = 0;
+    u32 frac = 0, wl = 0, wl4 = 0;
     for (u32 j = 0; j < CHUNK / 128; ++j) {
         uint4 v[8];
         if (RD == 2) {
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256, 4) mixed(const uint4 *__restrict__ in, ui
             acc.x = x;
         }
         frac += 233;
-        const bool w = WR != 9 && frac >= 256 && wl < 29;   // same for all lanes here (uniform rate)
+        const bool w = WR != 9 && WR != 4 && frac >= 256 && wl < 29;   // same for all lanes here (uniform rate)
         if (w) {
             frac -= 256;
             ++wl;
@@ -48,10 +48,29 @@ __global__ void __launch_bounds__(256, 4) mixed(const uint4 *__restrict__ in, ui
                 for (int h = 0; h < 2; ++h)
                     for (int r = 0; r < 4; ++r)
                         out[((c & ~3ull) + r + 1) * (SLOT / 16) - wl * 8 + h * 4 + (lane & 3u)] = make_uint4(acc.x + r, acc.y, h, v[r].x);
-            } else {
+            } else if (WR == 3) {
                 uint4 *p = out + (c + 1) * (SLOT / 16) - wl * 8;
                 for (int i = 0; i < 4; ++i) p[i + 4] = make_uint4(acc.x + i, acc.y, acc.z, v[i].x);
             }
+        }
+        if (WR == 4) {
+            // the encoder's shape: lanes complete their lines at different steps; at a step the quads run four rounds,
+            // round r stores the whole line of quad lane r (if it has one) as two 64-byte requests, lane j = pieces j, j+4
+            const u32 phase = (u32)((c * 2654435761ull) >> 7) & 1u;   // desynchronise the lanes
+            const bool mine = (((j + phase) & 1u) == 0) && (wl4 < 29);  // a line every other step ~ 0.5 per step
+#define QB(V, R) (u32) __builtin_amdgcn_mov_dpp((int)(V), (R) * 0x55, 0xF, 0xF, true)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const u32 mi = mine ? 1u : 0u;
+                const u32 f = r == 0 ? QB(mi, 0) : r == 1 ? QB(mi, 1) : r == 2 ? QB(mi, 2) : QB(mi, 3);
+                const u32 w_s = r == 0 ? QB(wl4, 0) : r == 1 ? QB(wl4, 1) : r == 2 ? QB(wl4, 2) : QB(wl4, 3);
+                if (f) {
+                    uint4 *p = out + ((c & ~3ull) + r + 1) * (SLOT / 16) - (w_s + 1) * 8 + (lane & 3u);
+                    p[0] = make_uint4(acc.x + r, acc.y, 0, v[r].x);
+                    p[4] = make_uint4(acc.x + r, acc.y, 1, v[r].y);
+                }
+            }
+            if (mine) ++wl4;
         }
         if (WR == 3 && (j & 1) && wl) {  // the other half, a step later
             uint4 *p = out + (c + 1) * (SLOT / 16) - wl * 8;
@@ -91,6 +110,9 @@ int main() {
     TP("read per-lane, write cooperative whole lines", 0, 1, 600)
     TP("read cooperative, write cooperative whole lines", 1, 1, 400)
     TP("read cooperative, write cooperative whole lines", 1, 1, 600)
+    TP("read per-lane, write quad whole lines unsynchronised", 0, 4, 0)
+    TP("read per-lane, write quad whole lines unsynchronised", 0, 4, 400)
+    TP("read per-lane, write quad whole lines unsynchronised", 0, 4, 600)
     TP("read per-lane, no writes", 0, 9, 400)
     TP("read per-lane, no writes", 0, 9, 600)
     return 0;
