@@ -197,10 +197,16 @@ struct AnsBackWriterL {
     u32 hi, lo;   // the window
     u32 room;     // 32 - (number of pending bits), as an unsigned counter: a push that BORROWS completed a word
     u32 wa;       // LDS byte address (from the ring base) of the word that completes next: base | offset 0..252
-    u32 th4;      // 124 or 252: offset of the FIRST word of the oldest unflushed line (top of its half)
+    u32 th4;      // ring offset of the FIRST word (highest address) of the oldest unflushed line
     u32 base;     // tid * LANE_BYTES (low 8 bits zero)
     u32 goff;     // byte offset (from the workgroup's output base) of the END of the next line to store
     u32 goff0;    // ... of the slot end
+
+    // Lanes that run in LOCKSTEP (equal symbol costs, e.g. a uniform table: every lane completes its words at the same
+    // steps) would all write the same ring offset -- the same bank, 32 ways.  Each lane's ring is therefore rotated by
+    // 16 * (lane mod 16) bytes: whole pieces, so a piece stays one aligned 16-byte read; lockstep lanes then spread over
+    // 8 bank groups (4-way, which ds_write_b32 half hides) and a line may wrap around the end of its ring.
+    static __device__ __forceinline__ u32 rot_of(u32 tid) { return 16u * (tid & 15u); }
 
     __device__ __forceinline__ u32 pend4() const { return (th4 - wa) & 255u; }  // 4 * completed words not yet stored (< 256)
 
@@ -208,8 +214,8 @@ struct AnsBackWriterL {
         hi = lo = 0;
         room = 32;
         base = tid * LANE_BYTES;
-        wa = base | 124u;
-        th4 = 124;
+        th4 = (124u + rot_of(tid)) & 255u;
+        wa = base | th4;
         goff = goff0 = slot_end_off;
     }
     // the low k bits of v go in front of the stream; k < 32, bits of v above bit k are ignored
@@ -240,27 +246,32 @@ struct AnsBackWriterL {
         }
     }
     template <int R>
-    __device__ __forceinline__ void quad_round(const char *lds, u8 *wg_out, u32 f, u32 qj, u32 j16) const {
+    __device__ __forceinline__ void quad_round(const char *lds, u8 *wg_out, u32 f, u32 qbase, u32 j16) const {
         if (scl_quad_bcast<R>(f)) {  // all four lanes of the quads whose lane R has a complete line
-            const u32 half = scl_quad_bcast<R>(th4) - 124u;  // 0 or 128: which half of the source's ring
+            // lowest address of the source's line inside its ring: 124 bytes below its first word, modulo the ring
+            const u32 l0 = scl_quad_bcast<R>(th4) + (132u + j16);  // (th4 - 124 + 16 j) mod 256, the +256 keeps it positive
             const u32 go_s = scl_quad_bcast<R>(goff);
-            const char *r = lds + (qj + half) + R * LANE_BYTES;
-            const uint4 q0 = *reinterpret_cast<const uint4 *>(r), q1 = *reinterpret_cast<const uint4 *>(r + 64);
+            const char *r = lds + qbase + R * LANE_BYTES;
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(r + (l0 & 255u));
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(r + ((l0 + 64u) & 255u));
             u8 *p = wg_out + (go_s - 128u + j16);
+#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
+#else
+            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
+#endif
         }
     }
     // WAVE-UNIFORM call (all 64 lanes), at least every 64 symbols: <= 26 new words on top of <= 31 pending
     __device__ __forceinline__ void flush_quad(char *lds, u8 *wg_out, u32 tid) {
         const u32 f = pend4() >= 128u ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(f != 0)) {
-            const u32 j = tid & 3u;
-            const u32 qj = (tid & ~3u) * LANE_BYTES + 16u * j, j16 = 16u * j;
-            quad_round<0>(lds, wg_out, f, qj, j16);
-            quad_round<1>(lds, wg_out, f, qj, j16);
-            quad_round<2>(lds, wg_out, f, qj, j16);
-            quad_round<3>(lds, wg_out, f, qj, j16);
+            const u32 qbase = (tid & ~3u) * LANE_BYTES, j16 = 16u * (tid & 3u);
+            quad_round<0>(lds, wg_out, f, qbase, j16);
+            quad_round<1>(lds, wg_out, f, qbase, j16);
+            quad_round<2>(lds, wg_out, f, qbase, j16);
+            quad_round<3>(lds, wg_out, f, qbase, j16);
             if (f) {
                 goff -= 128u;
                 th4 ^= 128u;
@@ -270,11 +281,12 @@ struct AnsBackWriterL {
     // the lane's own stores (ragged batches, partial waves): one line = eight 16-byte stores
     __device__ __forceinline__ void flush_lane(char *lds, u8 *wg_out) {
         if (pend4() >= 128u) {
-            const uint4 *r = reinterpret_cast<const uint4 *>(lds + base + (th4 - 124u));
+            const char *r = lds + base;
+            const u32 l0 = th4 + 132u;
             uint4 *p = reinterpret_cast<uint4 *>(wg_out + (goff - 128u));
             uint4 q[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = r[i];
+            for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4 *>(r + ((l0 + 16u * i) & 255u));
 #pragma unroll
             for (int i = 0; i < 8; ++i) p[i] = q[i];
             goff -= 128u;

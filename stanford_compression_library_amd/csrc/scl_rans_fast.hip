@@ -81,6 +81,9 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt
 struct Entries4 {
     uint4 e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
+#ifdef RF_ABLATE_NOCONFLICT  // timing experiment: every lane reads the entries of (lane-independent) symbols -> broadcast, no bank conflict
+        w = (u32)__builtin_amdgcn_readfirstlane((int)w);
+#endif
         e[0] = *reinterpret_cast<const uint4 *>(tab + ((w << 4) & 0xFF0u));
         e[1] = *reinterpret_cast<const uint4 *>(tab + ((w >> 4) & 0xFF0u));
         e[2] = *reinterpret_cast<const uint4 *>(tab + ((w >> 12) & 0xFF0u));
@@ -170,17 +173,39 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
     // One 128-byte line per tile.
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
+#ifndef RF_COOP_LOAD
+#define RF_COOP_LOAD 0
+#endif
+    // RF_COOP_LOAD = 1 (experiment): whole waves of equally long chunks load their 64 lines cooperatively (instruction i
+    // = the lines of the lanes l0 + 8 i, lane (l0, k) the k-th 16-byte piece) and transpose them in registers
+    const u32 lane = threadIdx.x & 63u;
+    const bool coop_in = RF_COOP_LOAD && coop_out && n_lines != 0;
+    const uint4 *cp16 = reinterpret_cast<const uint4 *>(sym + (c - lane + (lane & 7u)) * sym_stride) + (lane >> 3);
+    const u64 step16 = sym_stride >> 1;  // 8 rows further, in 16-byte units
     Line128 cur, nxt;
     Entries4 pre;
     if (n_lines) {
-        cur.load(src16);
+        if (coop_in) {
+            cur.load_coop(cp16, step16);
+            scl_transpose8(cur.v);
+        } else {
+            cur.load(src16);
+        }
         pre.load(cur.v[0].x, tab);
     }
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
         // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
         // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
-        nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+#if RF_ABLATE & 8  // timing experiment 8: no input loads after the first line
+        nxt = cur;
+        asm volatile("" : "+v"(nxt.v[0].x));
+#else
+        if (coop_in)
+            nxt.load_coop(cp16 + 8 * min(t + 1, n_lines - 1), step16);
+        else
+            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+#endif
         // straight-line code for the whole line: an inner loop holding only stores would make the compiler drain vmcnt
         // in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
 #pragma unroll
@@ -195,6 +220,7 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
             if ((i & 3) == RF_FLUSH_PHASE) RF_FLUSH();
         }
         cur = nxt;
+        if (coop_in) scl_transpose8(cur.v);
         pre.load(cur.v[0].x, tab);
     }
     u32 i = n_lines << 7;
