@@ -4,7 +4,7 @@
 // Same bit stream as the generic kernels in scl_rans.hip (and as reference rANS.py:186-210 / :270-297);
 // what changes is how a lane spends its instructions:
 //
-//  encode, per symbol (one 16-byte LDS table read):
+//  encode, per symbol (one 16-byte LDS table read, issued one word = four symbols ahead of its use):
 //    k     = k0[s] + (x >= thresh[s])                    closed form of shrink_state's while-loop
 //                                                         (rANS.py:149-161; tANS.py:74-86 gives the same rule)
 //    field = low k bits of x;  xs = x >> k
@@ -12,8 +12,9 @@
 //            with rcp = ceil(2^(nsb+s) / f), s = ceil(log2 f): exact for every x < 2^nsb
 //            (error term x*e/(f*2^(nsb+s+k)) < 2^-(s+k) <= 1/(f*2^k))
 //    x     = xs + c[s] + q*(M - f[s])                     == (xs//f)*M + c + xs%f  (rANS.py:138-147)
-//    Two fields are merged before they touch the 32-bit accumulator; completed big-endian words go to a
-//    per-lane LDS ring and leave as whole 128-byte lines, back to front (AnsBackWriter, scl_ans_fast_io.h).
+//    The field is never extracted: v_alignbit shifts the low k bits of x straight into a 64-bit bit window; completed
+//    big-endian words go to a 64-word per-lane LDS ring and leave as whole 128-byte lines, back to front, stored by the
+//    four lanes of the source lane's quad (AnsBackWriterL, scl_ans_fast_io.h).
 //  decode, per symbol (one 8-byte LDS table read, slot -> {f | sym << 24, slot - c}):
 //    x  = (x >> m)*f + (slot - c)                          rans_base_decode_step (rANS.py:234-249)
 //    nb = clz(x) - (32 - nsb);  x = (x << nb) | next nb bits   closed form of expand_state (:251-260),
