@@ -16,6 +16,9 @@
 #ifndef RF_ABLATE
 #define RF_ABLATE 0
 #endif
+#ifndef RD_ABLATE
+#define RD_ABLATE 0
+#endif
 
 
 // Instruction selection follows profiles/r01_ubench_valu_issue_cost.txt: on gfx950 only
@@ -383,7 +386,11 @@ struct CoopLineStore {
         for (int j = 0; j < 8; ++j) {
             typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
             const u32x4_nt t = {a[j].x, a[j].y, a[j].z, a[j].w};
+#if RD_ABLATE & 1  // timing experiment: no global stores
+            asm volatile("" : : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+#else
             __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(base + (u64)(8 * j) * stride + pos));
+#endif
         }
     }
 };
@@ -413,14 +420,18 @@ struct AnsBitReader {
     const uint4 *base;
     u64 n_blocks16;  // readable 16-byte blocks
     u64 next_line;   // index of the next 128-byte line to prefetch
+#if RD_ABLATE & 2
+    u64 abl_j0;
+#endif
     uint4 pf[8];     // prefetched line: its two 64-byte halves enter the ring one at a time
     u32 stage;       // 0: the lower half of pf is next, 1: the upper half
     u32 ra;          // LDS byte address of the next ring word to read (thread column, wraps inside the ring)
     u32 wa;          // LDS byte address of the ring half that is filled next
-    u32 nrd, nwr;    // words read from / written to the ring
+    u32 nwr;         // words written to the ring (the words READ follow from it and the two ring positions: nrd())
     u32 A, B;        // 64-bit window, big-endian words
-    int sh;          // lookahead = low32((A:B) >> sh); sh in [0,31]
-    u32 bias;        // consumed bits = 32*nrd - sh - bias
+    u32 sh;          // lookahead = low32((A:B) >> sh); sh in [0,31].  Unsigned on purpose: advance() takes the BORROW of
+                     // its subtraction as "the window crossed a word" (v_sub_co + branch on VCC, no compare)
+    u32 bias;        // consumed bits = 32*nrd() - sh - bias
 
     __device__ __forceinline__ void load_line(u64 j) {  // whole 128-byte line: one HBM burst instead of two
 #pragma unroll
@@ -460,19 +471,26 @@ struct AnsBitReader {
     __device__ __forceinline__ u32 next_word(const char *lds) {
         const u32 v = *reinterpret_cast<const u32 *>(lds + ra);
         ra = (ra + THREADS * 4) & (RING_BYTES - 1);
-        ++nrd;
         return v;
     }
+    // words still ahead of the reader, minus one, in ring-address units: `wa` is the half that is filled next, i.e.
+    // the row after the newest word; the reader never runs dry, so a distance of 0 rows means 32
+    __device__ __forceinline__ u32 ahead_m1() const { return (wa - ra - THREADS * 4) & (RING_BYTES - 1); }
+    __device__ __forceinline__ u32 nrd() const { return nwr - (ahead_m1() / (THREADS * 4) + 1); }
     // call at least every 16 symbols (<= 6 words consumed in between)
     __device__ __forceinline__ void maybe_refill(char *lds) {
-        if (nwr - nrd <= 16) {
+        if (ahead_m1() < 16 * THREADS * 4) {  // 16 words or fewer ahead: the reader has left the older half
             if (stage == 0) {
                 push_half(lds, pf[0], pf[1], pf[2], pf[3]);
                 stage = 1;
             } else {
                 push_half(lds, pf[4], pf[5], pf[6], pf[7]);
                 stage = 0;
+#if RD_ABLATE & 2  // timing experiment: after the header every lane keeps re-reading two lines (cache hits; decodes garbage)
+                load_line(abl_j0 + (next_line++ & 1));
+#else
                 load_line(next_line++);
+#endif
             }
         }
     }
@@ -494,10 +512,12 @@ struct AnsBitReader {
         push_half(lds, pf[4], pf[5], pf[6], pf[7]);
         load_line(j0 + 1);
         next_line = j0 + 2;
+#if RD_ABLATE & 2
+        abl_j0 = j0;
+#endif
         stage = 0;
         const u32 w0 = (u32)(bit_off >> 5) & 31u;
         ra = tid * 4 + w0 * THREADS * 4;
-        nrd = w0;
         // a stream that starts in the upper half of its line has fewer than 17 words ahead of it: top the ring
         // up before the first word is read (the lower half of the ring is already behind the read position)
         maybe_refill(lds);
@@ -510,15 +530,14 @@ struct AnsBitReader {
         } else {
             A = first;
             B = next_word(lds);
-            sh = 32 - (int)pos;
+            sh = 32 - pos;
         }
-        bias = 32 * nrd - (u32)sh;  // consumed == 0 here
+        bias = 32 * nrd() - sh;  // consumed == 0 here
     }
-    __device__ __forceinline__ u32 consumed() const { return 32 * nrd - (u32)sh - bias; }
-    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
+    __device__ __forceinline__ u32 consumed() const { return 32 * nrd() - sh - bias; }
+    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, sh); }
     __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
-        sh -= (int)nb;
-        if (sh < 0) {
+        if (__builtin_usub_overflow(sh, nb, &sh)) {
             A = B;
             B = next_word(lds);
             sh += 32;

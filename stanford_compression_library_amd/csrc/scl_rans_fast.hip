@@ -276,15 +276,23 @@ struct RfGenM {  // run-time constants of the any-total decoder
     double inv_m;
     u32 m, l;
 };
+// `lk` is updated to the lookahead that remains after the symbol (bits are consumed from its top).
 template <int ML_T, int CB_T>
-__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt,
+__device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt,
                                                 const RfGenM &rf_gen) {
     if (ML_T > 0 && CB_T == 3) {
+        // Top-aligned state X = x << 3 | three bits of lookahead (don't care): one 64-bit shift of xn:lookahead by
+        // cl = clz(xn) renormalises; its high word is the new X, its low word the lookahead shifted by cl -- three bits
+        // more than were read (cl - 3) -- so the lookahead that REMAINS is alignbit(high, low, 3): one instruction
+        // instead of computing cl - 3 and shifting again.  `used` is cl here (the caller subtracts the 3 per symbol once
+        // per pair).
         const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ML_T) - 1u) << 3)));
         const u32 xn = __umul24(x >> (ML_T + 3), e.x) + e.y;
         const u32 cl = (u32)__builtin_clz(xn);
-        x = (u32)(((((u64)xn) << 32) | lk) << cl >> 32);  // v_lshlrev_b64: top-aligned again (low 3 bits = look-ahead)
-        used = cl - 3;
+        const u64 t = ((((u64)xn) << 32) | lk) << cl;  // v_lshlrev_b64
+        x = (u32)(t >> 32);
+        lk = __builtin_amdgcn_alignbit(x, (u32)t, 3);
+        used = cl;
         return e.x;
     }
     if (ML_T < 0) {
@@ -302,6 +310,7 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
         const u32 lt = ((y >> (cb_rt + 1)) - rf_gen.l) >> 31;  // 1 iff the narrower candidate is below L
         x = y >> (cb_rt + 1 - lt);
         used = cl - cb_rt - 1 + lt;
+        lk <<= used;
         return e.x;
     }
     const u32 ML = ML_T > 0 ? (u32)ML_T : ml_rt, CB = ML_T > 0 ? (u32)CB_T : cb_rt;
@@ -311,6 +320,7 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 lk, u32 &used, const
     const u32 y = __builtin_amdgcn_alignbit(x, lk, 32 - cl);  // (x << cl) | (lk >> (32 - cl)), cl in [1,31]
     x = y >> CB;                                              // keep nb = cl - CB new bits
     used = cl - CB;
+    lk <<= used;
     return e.x;
 }
 
@@ -324,11 +334,13 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
         u32 o = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const u32 lk = r.look();
+            u32 lk = r.look();
             u32 ua, ub;
             const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt, rf_gen);
-            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk << ua, ub, tab, ml_rt, cb_rt, rf_gen);
-            r.advance(lds, ua + ub);  // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead
+            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk, ub, tab, ml_rt, cb_rt, rf_gen);
+            // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead (the top-aligned variant reports clz, 3 more
+            // per symbol than it read)
+            r.advance(lds, (ML_T > 0 && CB_T == 3) ? ua + ub - 6u : ua + ub);
             o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
             o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
             // the chain through x is serial anyway; without this fence the compiler sinks all the byte inserts
@@ -357,8 +369,11 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
     const u32 M = P.M;
-    for (u32 i = threadIdx.x; i < M; i += THREADS)
-        reinterpret_cast<uint2 *>(s_lds)[i] = P.d_dec_tab[i];
+    constexpr u32 XSH = (ML_T > 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
+    for (u32 i = threadIdx.x; i < M; i += THREADS) {
+        const uint2 v = P.d_dec_tab[i];
+        reinterpret_cast<uint2 *>(s_lds)[i] = v;
+    }
     __syncthreads();
     const u64 c = (u64)blockIdx.x * THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -374,7 +389,6 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, P.size_bits);
     u32 x = r.get(lds, P.nsb);
-    constexpr u32 XSH = (ML_T > 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
     x <<= XSH;
     out_lens[c] = n;
     if (n > out_cap) {
@@ -392,9 +406,9 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
-        u32 used;
-        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, r.look(), used, tab, ml_rt, cb_rt, rf_gen);
-        r.advance(lds, used);
+        u32 used, lk1 = r.look();
+        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, lk1, used, tab, ml_rt, cb_rt, rf_gen);
+        r.advance(lds, used - XSH);
         dst[--i] = (u8)(e >> 24);
         if ((i & 3u) == 0) r.maybe_refill(lds);
     }
