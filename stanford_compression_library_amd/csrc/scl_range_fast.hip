@@ -73,6 +73,7 @@ struct RgOut {
             if (have_held) {  // second half of a line: store the whole 128 bytes at once
                 if (4 * (u64)nfl + 64 <= cap) {
                     uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+#ifndef RG_ABLATE_NOSTORE
                     p[0] = held[0];
                     p[1] = held[1];
                     p[2] = held[2];
@@ -81,6 +82,9 @@ struct RgOut {
                     p[5] = q1;
                     p[6] = q2;
                     p[7] = q3;
+#else
+                    asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
+#endif
                 } else {
                     overflow = 1;
                 }
