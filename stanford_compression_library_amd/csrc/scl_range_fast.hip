@@ -517,12 +517,14 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     md.inv_m = 1.0 / (double)P.M;
 
     u32 i = 0;
-    // 128 symbols per iteration: eight registers, one burst of eight 16-byte stores (a whole line).  (The wave-
-    // cooperative store of the rANS / tANS decoders, CoopLineStore, made this instruction-bound kernel 8 % slower.)
+    // 128 symbols per iteration: eight registers, one burst of eight 16-byte stores (a whole line).  The b loop must be
+    // unrolled in full (plain "#pragma unroll" gives up on a body of 16 symbols: a[] then lives in scratch memory, eight
+    // scratch stores and loads per line -- 1.44 instead of 1.35 ms).  (The wave-cooperative store of the rANS / tANS
+    // decoders, CoopLineStore, made this instruction-bound kernel 8 % slower.)
 #pragma nounroll
     for (; i + 128 <= n; i += 128) {
         uint4 a[8];
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int b = 0; b < 8; ++b) {
             u32 ow[4];
 #pragma unroll

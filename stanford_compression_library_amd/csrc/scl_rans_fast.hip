@@ -53,6 +53,12 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 // LDS per workgroup: 64 KiB ring + 4 KiB table = two workgroups per CU (2 waves per SIMD; 4 measured the same).
 typedef AnsBackWriterL<RF_THREADS> EncOut;
 #define RF_RING_BYTES (RF_THREADS * 256)
+#ifndef RF_FLUSH_MASK
+#define RF_FLUSH_MASK 3  // flush point every (mask + 1) * 16 symbols
+#endif
+#ifndef RF_WAVES
+#define RF_WAVES 2  // workgroups per CU = waves per SIMD
+#endif
 
 // v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
 // half-rate instructions); one full-rate add feeding the multiply-add is cheaper
@@ -62,33 +68,61 @@ __device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
     return d;
 }
 
-// One symbol.  Table entry {rcp, thresh, c, (M-f) | k1 << 24} with k1 = k0 + 1.  MSH = m - (32 - nsb) + 1 so that
-// q = mulhi(x, rcp) >> (MSH - [x < thresh]).  s + k0 == m for every symbol (k0 = m - bit_width(f) or m - log2 f,
-// s = ceil(log2 f)): the quotient shift s + k - (32 - nsb) is therefore m - (32 - nsb) + (x >= thresh), and the
-// pre-shift of x disappears.  The k released bits are never extracted: push() takes the low k bits of x by itself.
-template <int MSH_T>
-__device__ __forceinline__ u32 rf_encode_entry(u32 &x, const uint4 e, u32 msh_rt, EncOut &o) {  // returns k
-    // run-time form: msh_rt = MSH | pre << 8.  Tables so small that m < 32 - nsb would need a negative MSH; they
-    // shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
-    const u32 MSH = MSH_T ? (u32)MSH_T : (msh_rt & 0xFFu);
-    const u32 neg = (x - e.y) >> 31;  // 1 iff x < thresh (both < 2^31)
-    const u32 k = (e.w >> 24) - neg;
-    const u32 q = rf_umulhi(MSH_T ? x : (x << (msh_rt >> 8)), e.x) >> (MSH - neg);
+// One symbol.  Table entry {rcp, (M-f) | k_lo << 24, c, 0}.
+// MSH = m - (32 - nsb) + 1 as before; q0 = mulhi(x, rcp) >> (MSH - 1) = floor(x / (f 2^k_lo)) is exact for EVERY
+// x < 2^nsb (rans_fast_build_tables), so the test "x >= thresh = 2 RF f 2^k_lo" is simply q0 >= 2 RF: no threshold in
+// the table, no subtraction -- pos = q0 >> (r + 1) (q0 < 4 RF), k = k_lo + pos, q = floor((x >> k) / f) = q0 >> pos
+// (nested floors).  The k released bits are never extracted: push() takes the low k bits of x by itself.
+struct __attribute__((aligned(16))) EncEntry {
+    u32 rcp, mfk, c, pad;
+};
+template <int MSH_T, int R_T>
+__device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns k
+    // run-time form: msh_rt = MSH | pre << 8 | r << 16.  Tables so small that m < 32 - nsb would need a negative MSH;
+    // they shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
+    // keep the table read a ds_read_b128: the compiler would shrink it to the 12 bytes in use, and ds_read_b96 is far
+    // slower on this chip (whole kernel 0.58 -> 0.68 ms)
+    asm volatile("" : : "v"(e.pad));
+    const u32 mh = rf_umulhi(MSH_T ? x : (x << ((msh_rt >> 8) & 0xFFu)), e.rcp);
+    u32 q0, pos;
+    if (MSH_T) {
+        static_assert(MSH_T == 0 || MSH_T + R_T < 32, "shift out of range");
+        q0 = mh >> (MSH_T - 1);
+        pos = mh >> (MSH_T + R_T);  // = q0 >> (r + 1), straight from the product
+    } else {
+        q0 = mh >> ((msh_rt & 0xFFu) - 1u);
+        pos = q0 >> ((msh_rt >> 16) + 1u);
+    }
+    const u32 k = (e.mfk >> 24) + pos;
     o.push(x, k);
-    x = rf_mad24(q, e.w, (x >> k) + e.z);  // v_mad_u32_u24 reads only the low 24 bits of e.w
+    x = rf_mad24(q0 >> pos, e.mfk, (x >> k) + e.c);  // v_mad_u32_u24 reads only the low 24 bits of e.mfk
     return k;
 }
 
 struct Entries4 {
-    uint4 e[4];
+    EncEntry e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
 #ifdef RF_ABLATE_NOCONFLICT  // timing experiment: every lane reads the entries of (lane-independent) symbols -> broadcast, no bank conflict
         w = (u32)__builtin_amdgcn_readfirstlane((int)w);
 #endif
-        e[0] = *reinterpret_cast<const uint4 *>(tab + ((w << 4) & 0xFF0u));
-        e[1] = *reinterpret_cast<const uint4 *>(tab + ((w >> 4) & 0xFF0u));
-        e[2] = *reinterpret_cast<const uint4 *>(tab + ((w >> 12) & 0xFF0u));
-        e[3] = *reinterpret_cast<const uint4 *>(tab + ((w >> 20) & 0xFF0u));
+        // byte 0 like the other three: one SDWA shift (the compiler turns (w & 0xFF) << 4 into a shift and a mask)
+        u32 a0;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+            : "=v"(a0)
+            : "v"(4u), "v"(w));
+#ifdef RF_ABLATE_B64  // timing experiment: 8-byte table reads (c = 0: garbage output, same flow)
+#define RF_LOAD_ENTRY(dst, addr)                                                \
+    do {                                                                        \
+        const uint2 t2 = *reinterpret_cast<const uint2 *>(tab + (addr));        \
+        dst.rcp = t2.x, dst.mfk = t2.y, dst.c = 0, dst.pad = 0;                 \
+    } while (0)
+#else
+#define RF_LOAD_ENTRY(dst, addr) dst = *reinterpret_cast<const EncEntry *>(tab + (addr))
+#endif
+        RF_LOAD_ENTRY(e[0], a0);
+        RF_LOAD_ENTRY(e[1], (w >> 4) & 0xFF0u);
+        RF_LOAD_ENTRY(e[2], (w >> 12) & 0xFF0u);
+        RF_LOAD_ENTRY(e[3], (w >> 20) & 0xFF0u);
     }
 };
 
@@ -102,7 +136,7 @@ struct Entries4 {
 // on exit: the table reads of a word are issued one word ahead of their use, in program order, so that their LDS latency
 // (100+ clocks with the bank conflicts of a random symbol mix) runs under the arithmetic of the current word instead of
 // in front of it -- with two waves per SIMD there is nobody else to hide it.
-template <int CHECK_SYM, int MSH_T>
+template <int CHECK_SYM, int MSH_T, int R_T>
 __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 &pre, u32 &x, EncOut &o, u32 &bad, u32 chk_c,
                                             char *lds, const char *tab, u32 msh_rt) {
     const u32 wv[5] = {v.x, v.y, v.z, v.w, next_w};
@@ -116,17 +150,17 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
-        const u32 k0 = rf_encode_entry<MSH_T>(x, cur.e[0], msh_rt, o);
-        const u32 k1 = rf_encode_entry<MSH_T>(x, cur.e[1], msh_rt, o);
+        const u32 k0 = rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o);
+        const u32 k1 = rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o);
         o.check(lds, k0 + k1);
-        const u32 k2 = rf_encode_entry<MSH_T>(x, cur.e[2], msh_rt, o);
-        const u32 k3 = rf_encode_entry<MSH_T>(x, cur.e[3], msh_rt, o);
+        const u32 k2 = rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o);
+        const u32 k3 = rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o);
         o.check(lds, k2 + k3);
     }
 }
 
-template <int CHECK_SYM, int MSH_T>
-__global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+template <int CHECK_SYM, int MSH_T, int R_T>
+__global__ void __launch_bounds__(RF_THREADS, RF_WAVES) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
                                                                         u64 n_chunks, u8 *__restrict__ out,
@@ -138,7 +172,10 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
 #ifndef RF_TAB_COPIES
 #define RF_TAB_COPIES 1
 #endif
-    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + RF_RING_BYTES];
+#ifndef RF_LDS_PAD
+#define RF_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
+#endif
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + RF_RING_BYTES + RF_LDS_PAD];
     char *lds = s_lds + RF_TAB_COPIES * 256 * 16;
     // RF_TAB_COPIES = 2 (experiment): odd lanes read a second copy of the table -- the 16 lanes of a ds_read_b128 pass
     // then spread over twice the banks
@@ -151,7 +188,7 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    const u32 msh_rt = P.enc_msh;  // MSH | pre << 8, see rans_fast_build_tables
+    const u32 msh_rt = P.enc_msh;  // MSH | pre << 8 | r << 16, see rans_fast_build_tables
     // offsets from the workgroup's first slot (the launch guarantees RF_THREADS * out_stride < 2^32): the store address
     // is then a uniform base + one 32-bit register, which is also all a helper lane needs to know of its source
     u8 *wg_out = out + (u64)blockIdx.x * RF_THREADS * out_stride;
@@ -212,13 +249,13 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             // (the first word of the next line is only known once the prefetch has landed: its entries are read below)
-            rf_encode16<CHECK_SYM, MSH_T>(cur.v[i], i < 7 ? cur.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
+            rf_encode16<CHECK_SYM, MSH_T, R_T>(cur.v[i], i < 7 ? cur.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
             // every 64 symbols (<= 26 new words on top of <= 31 pending, ring of 64) -- after the symbols 32 and 96 of the
             // line, NOT 64 and 128: the wait for the prefetched line at the end of the iteration is an s_waitcnt vmcnt(0)
             // (loads and stores share one in-order counter and the stores sit in conditional code, so the compiler cannot
             // count them), i.e. it also waits for every store issued so far to COMPLETE; stores issued just before it
             // cost their whole round trip
-            if ((i & 3) == RF_FLUSH_PHASE) RF_FLUSH();
+            if ((i & RF_FLUSH_MASK) == (RF_FLUSH_PHASE & RF_FLUSH_MASK)) RF_FLUSH();
         }
         cur = nxt;
         if (coop_in) scl_transpose8(cur.v);
@@ -228,13 +265,13 @@ __global__ void __launch_bounds__(RF_THREADS, 2) rans_encode_fast_kernel(RansFas
     for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
         const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
         pre.load(v.x, tab);
-        rf_encode16<CHECK_SYM, MSH_T>(v, 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
+        rf_encode16<CHECK_SYM, MSH_T, R_T>(v, 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
         RF_FLUSH();
     }
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
-        o.check(lds, rf_encode_entry<MSH_T>(x, *reinterpret_cast<const uint4 *>(tab + a), msh_rt, o));
+        o.check(lds, rf_encode_entry<MSH_T, R_T>(x, *reinterpret_cast<const EncEntry *>(tab + a), msh_rt, o));
         if ((i & 15u) == 15u) RF_FLUSH();
     }
     RF_FLUSH();
@@ -472,7 +509,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     //   <= mp + 1), so the shift after the multiply-high is MSH - [x < thresh] with MSH = C - 32 -- or, when C <= 32,
     //   MSH = 1 after x was shifted left by pre = 33 - C.  For a power-of-two total this is rcp = ceil(2^(nsb+s)/f).
     const u32 C = r + 2 * mp + 2;
-    const u32 enc_msh = (C >= 33) ? (C - 32) : (1u | ((33 - C) << 8));
+    const u32 enc_msh = ((C >= 33) ? (C - 32) : (1u | ((33 - C) << 8))) | (r << 16);
     std::vector<uint4> enc(256);
     std::vector<uint2> dec(M);
     for (u32 s = 0; s < 256; ++s) {
@@ -491,7 +528,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
         if (E < nsb + ceil_log2_u32(f) || E > 62) return SCL_OK;  // cannot happen (see above)
         const u64 rcp = ((1ull << E) + f - 1) / f;
         if (rcp >> 32) return SCL_OK;
-        enc[s] = make_uint4((u32)rcp, (u32)thresh, c, (M - f) | (k1 << 24));
+        enc[s] = make_uint4((u32)rcp, (M - f) | (k_lo << 24), c, 0u);
     }
     for (u32 s = 0; s < D.K; ++s)
         for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = make_uint2(h_freq[s] | (s << 24), j);
@@ -520,9 +557,10 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    const int msh = (m->fdev.enc_msh >> 8) ? 0 : (int)m->fdev.enc_msh;  // literal form only without a pre-shift
+    // literal form: only without a pre-shift, and for the one (MSH, r) pair that is instantiated
+    const int msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : 0;
 #define RF_LAUNCH_ENC(CHECK, MSH)                                                                              \
-    hipLaunchKernelGGL((rans_encode_fast_kernel<CHECK, MSH>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<CHECK, MSH, (MSH ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
                        d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,  \
                        d_status)
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants

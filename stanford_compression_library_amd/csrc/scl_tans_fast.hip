@@ -24,6 +24,9 @@ struct TfSym {
 
 __device__ __forceinline__ TfSym tf_encode_symbol(u32 &x, u32 addr, const char *sym_tab, const char *lds) {
     const uint4 e = *reinterpret_cast<const uint4 *>(sym_tab + addr);
+    // keep the read a ds_read_b128: shrunk to the 12 bytes in use it becomes a ds_read_b96, which is far slower on this
+    // chip (rANS encoder: 0.58 -> 0.68 ms with b96 table reads)
+    asm volatile("" : : "v"(e.w));
     const u32 neg = (x - e.x) >> 31;  // 1 iff x < shrink_state_thresh_table[s]
     const u32 nb = e.z - neg;         // shrink_state_num_out_bits_base_table[s] (+1 above the threshold)
     TfSym r;
