@@ -362,7 +362,11 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, cons
 }
 
 // 16 symbols, last first, into one 16-byte register (byte i of the result = symbol i of the block)
-template <int ML_T, int CB_T, typename DecIn>
+// REFILL: top the input ring up afterwards.  The ring wants that at least every 32 symbols (32 x 13 bits = 13 words:
+// a check that found 17 words ahead and did nothing still leaves 4); the line loop asks after every second block,
+// because a check costs the wave BOTH refill bodies (some lane is always at either stage: 2 x 16 byte swaps and ring
+// writes, plus the loads) whether or not a given lane needed one.
+template <int ML_T, int CB_T, bool REFILL = true, typename DecIn>
 __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt,
                                              const RfGenM &rf_gen) {
     u32 ow[4];
@@ -386,7 +390,7 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
         }
         ow[d] = o;
     }
-    r.maybe_refill(lds);
+    if (REFILL) r.maybe_refill(lds);
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
@@ -463,7 +467,9 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     while (i) {
         uint4 a[8];
 #pragma unroll
-        for (int b = 7; b >= 0; --b) a[b] = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
+        for (int b = 7; b >= 0; --b)
+            a[b] = (b & 1) ? rf_decode16<ML_T, CB_T, false>(x, r, lds, tab, ml_rt, cb_rt, rf_gen)
+                           : rf_decode16<ML_T, CB_T, true>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 128;
         if (cs.on) {
             cs.store(a, i);
