@@ -182,7 +182,7 @@ def rocprof_kernel_names(args, freq):
         r = int(args.range_factor).bit_length() - 1
         default_shape = (M == 4096 and r == 16)
         check = 0 if K == 256 else (1 if K <= 128 else 2)
-        enc = f"rans_encode_fast_kernel<{check}, {10 if default_shape else 0}>"
+        enc = f"rans_encode_fast_kernel<{check}, {'10, 16' if default_shape else '0, 0'}>"
         threads = 1024 if args.chunks > 2 * 256 * 256 else 256
         if M & (M - 1):
             dec = f"rans_decode_fast_kernel<-1, 0, {threads}>"
