@@ -182,7 +182,16 @@ def rocprof_kernel_names(args, freq):
         r = int(args.range_factor).bit_length() - 1
         default_shape = (M == 4096 and r == 16)
         check = 0 if K == 256 else (1 if K <= 128 else 2)
-        enc = f"rans_encode_fast_kernel<{check}, {'10, 16' if default_shape else '0, 0'}>"
+        # writer: scl_rans_fast.hip rf_use_slot_writer (fewer rounds with three workgroups per CU, no lockstep table)
+        import torch
+        w = -(-args.chunks // 256)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count if torch.cuda.is_available() else 256
+        lockstep = int(freq.max()) == int(freq.min())
+        slots = (not lockstep) and 3 * (-(-w // (3 * cus))) < 2 * (-(-w // (2 * cus)))
+        if os.environ.get("SCL_RANS_ENC_WRITER", "")[:1].upper() in ("L", "S"):
+            slots = os.environ["SCL_RANS_ENC_WRITER"][:1].upper() == "S"
+        enc = (f"rans_encode_fast_kernel<AnsBackWriter{'S' if slots else 'L'}<256>, {check}, "
+               f"{'10, 16' if default_shape else '0, 0'}>")
         threads = 1024 if args.chunks > 2 * 256 * 256 else 256
         if M & (M - 1):
             dec = f"rans_decode_fast_kernel<-1, 0, {threads}>"

@@ -195,6 +195,9 @@ __device__ __forceinline__ u32 scl_quad_bcast(u32 v) {  // value of lane R of th
 }
 template <int THREADS>
 struct AnsBackWriterL {
+    static constexpr u32 FLUSH_MASK = 3;   // the encoder's flush points: every (FLUSH_MASK + 1) x 16 symbols
+    static constexpr u32 FLUSH_PHASE = 1;  // ... after block 1 (mod 4) of a line
+    static constexpr u32 WG_PER_CU = 2;    // 64 KiB of rings + the 4 KiB table per 256 lanes
     static constexpr u32 LANE_BYTES = 256;                   // one 256-byte ring per lane, 256-byte aligned
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup
     u32 hi, lo;   // the window
@@ -305,6 +308,136 @@ struct AnsBackWriterL {
         for (u32 j = 0; j < np; ++j) {
             end32[-(i64)j - 1] = *reinterpret_cast<const u32 *>(lds + base + a);
             a = (a - 4u) & 252u;
+        }
+        const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
+        if (n) end32[-(i64)np - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
+        return (u64)(((goff0 - goff) >> 2) + np) * 32 + n;
+    }
+};
+
+// Round-2 back writer, three-workgroups-per-CU form: the same bit window and the same quad-cooperative line stores
+// over rings of 192 bytes = three 64-byte SLOTS per lane, so that three workgroups of 256 lanes fit a CU
+// (3 x (4 KiB table + 48 KiB)) -- a SIMD with two waves cannot cover their stalls (a wave issues at most one VALU
+// instruction per ~5 clocks: tools/ubench/valu_rate.hip), a third is worth 9 % of the rANS encoder's time.
+//   * A line is two slots, upper half then lower half (the stream grows downwards); slots never wrap, so a helper
+//     lane's two piece addresses are two DPP adds (source's slot offset + its own quad base + 16 j) -- cheaper than
+//     the 256-byte ring's modulo arithmetic.  No per-lane rotation: see the LOCKSTEP note below.
+//   * 48 words hold a line waiting for its flush point (<= 31 words) plus what 32 symbols add (<= 13): flush points
+//     are 32 symbols apart (FLUSH_MASK = 1).
+//   * The word pointer wraps at a non-power-of-two: v_cmp + v_cndmask + v_add instead of v_add + v_and_or.
+// LOCKSTEP: lanes whose symbols all cost the same number of bits (a table of equal frequencies) complete their words
+// at the same steps and write the same ring offset; with a lane stride of 192 bytes and no rotation that is 2 of the
+// 32 banks.  The launch code keeps such tables on AnsBackWriterL (whose rings are rotated per lane).
+template <int THREADS>
+struct AnsBackWriterS {
+    static constexpr u32 FLUSH_MASK = 1;
+    static constexpr u32 FLUSH_PHASE = 0;  // after blocks 0, 2, 4, 6 of a line: none just before its end (see the kernel)
+    static constexpr u32 WG_PER_CU = 3;
+    static constexpr u32 LANE_BYTES = 192;
+    static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;
+    u32 hi, lo;   // the window
+    u32 room;     // 32 - (number of pending bits): a push that BORROWS completed a word
+    u32 wo;       // ring offset (0..188) of the word that completes next; its LDS address is base + wo
+    u32 rhi, rlo; // ring offsets (0, 64 or 128) of the slots holding the upper / lower half of the oldest unflushed line
+    u32 base;     // tid * LANE_BYTES
+    u32 goff;     // byte offset (from the workgroup's output base) of the END of the next line to store
+    u32 goff0;    // ... of the slot end
+
+    // 4 * completed words not yet stored (<= 176): the line's first word is the top word of its upper slot
+    __device__ __forceinline__ u32 pend4() const {
+        const u32 t = rhi + 60u - wo;  // negative when the write offset is above the line's first word
+        return t + ((u32)((int)t >> 31) & LANE_BYTES);
+    }
+    __device__ __forceinline__ void init(u32 tid, u32 slot_end_off) {
+        hi = lo = 0;
+        room = 32;
+        base = tid * LANE_BYTES;
+        rhi = 128;
+        rlo = 64;
+        wo = 188u;
+        goff = goff0 = slot_end_off;
+    }
+    __device__ __forceinline__ void push(u32 v, u32 k) {  // the low k bits of v go in front of the stream; k < 32
+        lo = __builtin_amdgcn_alignbit(hi, lo, k);
+        hi = __builtin_amdgcn_alignbit(v, hi, k);
+    }
+    __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check
+        if (__builtin_usub_overflow(room, bits, &room)) {
+            const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
+            *reinterpret_cast<u32 *>(lds + (base + wo)) = __builtin_bswap32(word);
+            // (wo - 4) mod 192: only wo == 0 wraps, and wo - 4 is then a huge unsigned value -- one subtraction and one
+            // unsigned minimum against the constant 188
+            wo = min(wo - 4u, LANE_BYTES - 4u);
+            room += 32;
+        }
+    }
+    __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
+        if (w > 16) {
+            push(v, 16);
+            check(lds, 16);
+            push(v >> 16, w - 16);
+            check(lds, w - 16);
+        } else {
+            push(v, w);
+            check(lds, w);
+        }
+    }
+    template <int R>
+    __device__ __forceinline__ void quad_round(const char *lds, u8 *wg_out, u32 f, u32 qj, u32 j16) const {
+        if (scl_quad_bcast<R>(f)) {  // all four lanes of the quads whose lane R has a complete line
+            const char *r = lds + R * LANE_BYTES;
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(r + (scl_quad_bcast<R>(rlo) + qj));
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(r + (scl_quad_bcast<R>(rhi) + qj));
+            u8 *p = wg_out + (scl_quad_bcast<R>(goff) - 128u + j16);
+#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
+            *reinterpret_cast<uint4 *>(p) = q0;
+            *reinterpret_cast<uint4 *>(p + 64) = q1;
+#else
+            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
+#endif
+        }
+    }
+    __device__ __forceinline__ void line_done() {
+        goff -= 128u;
+        const u32 l = rlo;
+        rhi = min(l + 128u, l - 64u);   // (l - 64) mod 192
+        rlo = min(l + 64u, l - 128u);   // (l - 128) mod 192
+    }
+    // WAVE-UNIFORM call (all 64 lanes), at least every 32 symbols: <= 13 new words on top of <= 31 pending
+    __device__ __forceinline__ void flush_quad(char *lds, u8 *wg_out, u32 tid) {
+        const u32 f = pend4() >= 128u ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(f != 0)) {
+            const u32 j16 = 16u * (tid & 3u), qj = (tid & ~3u) * LANE_BYTES + j16;
+            quad_round<0>(lds, wg_out, f, qj, j16);
+            quad_round<1>(lds, wg_out, f, qj, j16);
+            quad_round<2>(lds, wg_out, f, qj, j16);
+            quad_round<3>(lds, wg_out, f, qj, j16);
+            if (f) line_done();
+        }
+    }
+    // the lane's own stores (ragged batches, partial waves): one line = eight 16-byte stores
+    __device__ __forceinline__ void flush_lane(char *lds, u8 *wg_out) {
+        if (pend4() >= 128u) {
+            const uint4 *a = reinterpret_cast<const uint4 *>(lds + base + rlo);
+            const uint4 *b = reinterpret_cast<const uint4 *>(lds + base + rhi);
+            uint4 *p = reinterpret_cast<uint4 *>(wg_out + (goff - 128u));
+            uint4 q[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = a[i], q[4 + i] = b[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = q[i];
+            line_done();
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds, u8 *wg_out) {  // per lane; returns the stream length in bits
+        flush_lane(lds, wg_out);
+        flush_lane(lds, wg_out);
+        u32 *end32 = reinterpret_cast<u32 *>(wg_out + goff);  // words go below this, newest at the lowest address
+        const u32 np = pend4() >> 2;                         // < 32 now
+        u32 a = rhi + 60u;
+        for (u32 j = 0; j < np; ++j) {
+            end32[-(i64)j - 1] = *reinterpret_cast<const u32 *>(lds + base + a);
+            a = min(a - 4u, LANE_BYTES - 4u);
         }
         const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
         if (n) end32[-(i64)np - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));

@@ -26,13 +26,12 @@
 // into registers, next line prefetched); DESIGN.md section 3.1 has the measurements that led there.
 #include <vector>
 
+#include <stdlib.h>
+
 #include "scl_ans_fast_io.h"
 #include "scl_rans_internal.h"
 
 #define RF_THREADS 256
-#ifndef RF_FLUSH_PHASE
-#define RF_FLUSH_PHASE 1
-#endif
 #ifndef RF_COOP_STORE
 #define RF_COOP_STORE 1  // 0 (timing experiment): every lane stores its own lines
 #endif
@@ -51,14 +50,11 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 //           bounds the kernel, tools/ubench/linecopy3.hip.)
 //   output: AnsBackWriterL (scl_ans_fast_io.h): bit window -> 64-word LDS ring per lane -> whole lines stored by quads.
 // LDS per workgroup: 64 KiB ring + 4 KiB table = two workgroups per CU (2 waves per SIMD; 4 measured the same).
-typedef AnsBackWriterL<RF_THREADS> EncOut;
-#define RF_RING_BYTES (RF_THREADS * 256)
-#ifndef RF_FLUSH_MASK
-#define RF_FLUSH_MASK 3  // flush point every (mask + 1) * 16 symbols
-#endif
-#ifndef RF_WAVES
-#define RF_WAVES 2  // workgroups per CU = waves per SIMD
-#endif
+// Two writers (scl_ans_fast_io.h): AnsBackWriterL, 256-byte rings, two workgroups per CU; AnsBackWriterS, 192-byte
+// rings in 64-byte slots, three workgroups per CU -- for batches that can populate a third wave per SIMD
+// (rans_fast_encode_launch).
+typedef AnsBackWriterL<RF_THREADS> EncOutL;
+typedef AnsBackWriterS<RF_THREADS> EncOutS;
 
 // v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
 // half-rate instructions); one full-rate add feeding the multiply-add is cheaper
@@ -76,7 +72,7 @@ __device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
 struct __attribute__((aligned(16))) EncEntry {
     u32 rcp, mfk, c, pad;
 };
-template <int MSH_T, int R_T>
+template <int MSH_T, int R_T, typename EncOut>
 __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns k
     // run-time form: msh_rt = MSH | pre << 8 | r << 16.  Tables so small that m < 32 - nsb would need a negative MSH;
     // they shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
@@ -136,7 +132,7 @@ struct Entries4 {
 // on exit: the table reads of a word are issued one word ahead of their use, in program order, so that their LDS latency
 // (100+ clocks with the bank conflicts of a random symbol mix) runs under the arithmetic of the current word instead of
 // in front of it -- with two waves per SIMD there is nobody else to hide it.
-template <int CHECK_SYM, int MSH_T, int R_T>
+template <int CHECK_SYM, int MSH_T, int R_T, typename EncOut>
 __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 &pre, u32 &x, EncOut &o, u32 &bad, u32 chk_c,
                                             char *lds, const char *tab, u32 msh_rt) {
     const u32 wv[5] = {v.x, v.y, v.z, v.w, next_w};
@@ -159,8 +155,11 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
     }
 }
 
-template <int CHECK_SYM, int MSH_T, int R_T>
-__global__ void __launch_bounds__(RF_THREADS, RF_WAVES) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+#ifndef RF_WAVES_ATTR
+#define RF_WAVES_ATTR
+#endif
+template <typename EncOut, int CHECK_SYM, int MSH_T, int R_T>
+__global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
                                                                         u64 n_chunks, u8 *__restrict__ out,
@@ -175,7 +174,7 @@ __global__ void __launch_bounds__(RF_THREADS, RF_WAVES) rans_encode_fast_kernel(
 #ifndef RF_LDS_PAD
 #define RF_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
 #endif
-    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + RF_RING_BYTES + RF_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + EncOut::RING_BYTES + RF_LDS_PAD];
     char *lds = s_lds + RF_TAB_COPIES * 256 * 16;
     // RF_TAB_COPIES = 2 (experiment): odd lanes read a second copy of the table -- the 16 lanes of a ds_read_b128 pass
     // then spread over twice the banks
@@ -255,7 +254,7 @@ __global__ void __launch_bounds__(RF_THREADS, RF_WAVES) rans_encode_fast_kernel(
             // (loads and stores share one in-order counter and the stores sit in conditional code, so the compiler cannot
             // count them), i.e. it also waits for every store issued so far to COMPLETE; stores issued just before it
             // cost their whole round trip
-            if ((i & RF_FLUSH_MASK) == (RF_FLUSH_PHASE & RF_FLUSH_MASK)) RF_FLUSH();
+            if ((i & EncOut::FLUSH_MASK) == EncOut::FLUSH_PHASE) RF_FLUSH();
         }
         cur = nxt;
         if (coop_in) scl_transpose8(cur.v);
@@ -518,6 +517,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     const u32 enc_msh = ((C >= 33) ? (C - 32) : (1u | ((33 - C) << 8))) | (r << 16);
     std::vector<uint4> enc(256);
     std::vector<uint2> dec(M);
+    u64 fixed_k_mass[32] = {0};  // total frequency of the symbols that ALWAYS release k bits (k_hi == k_lo), per k
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
         const u32 f = h_freq[src], c = h_cum[src];
@@ -535,7 +535,13 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
         const u64 rcp = ((1ull << E) + f - 1) / f;
         if (rcp >> 32) return SCL_OK;
         enc[s] = make_uint4((u32)rcp, (M - f) | (k_lo << 24), c, 0u);
+        if (s < D.K && k_hi == k_lo && k_lo < 32) fixed_k_mass[k_lo] += f;
     }
+    // lanes whose symbols nearly all release the same number of bits complete their words at the same steps
+    // (a table of equal frequencies does so exactly): AnsBackWriterS has no defence against that, AnsBackWriterL has
+    u64 top_mass = 0;
+    for (u32 k = 0; k < 32; ++k) top_mass = fixed_k_mass[k] > top_mass ? fixed_k_mass[k] : top_mass;
+    m->enc_lockstep = (4 * top_mass >= 3 * (u64)M) ? 1u : 0u;
     for (u32 s = 0; s < D.K; ++s)
         for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = make_uint2(h_freq[s] | (s << 24), j);
     hipError_t e = hipMalloc((void **)&m->d_enc_tab, 256 * sizeof(uint4));
@@ -559,16 +565,49 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     return SCL_OK;
 }
 
+// Which writer.  At equal occupancy the two run within noise of each other (the third wave per SIMD that AnsBackWriterS
+// makes room for is worth ~5 %, its longer word-emission block and doubled flush points cost as much), so the choice is
+// a matter of ROUNDS: a CU holds two workgroups of the L kernel (a round = 512 workgroups on this 256-CU chip, t) or
+// three of the S kernel (768 workgroups, ~1.5 t).  S is taken when it needs strictly less time by that count --
+// e.g. 513..768 workgroups (131 073..196 608 chunks: 0.467 -> 0.427 ms) -- and never for tables that drive the lanes in
+// lockstep.  1 024 workgroups (the headline batch) are two full rounds of L.  SCL_RANS_ENC_WRITER=L|S overrides (tests,
+// tools/ab_s.sh).
+static bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks) {
+    static const char *force = getenv("SCL_RANS_ENC_WRITER");
+    if (force && (force[0] == 'L' || force[0] == 'l')) return false;
+    if (force && (force[0] == 'S' || force[0] == 's')) return true;
+    if (m->enc_lockstep) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    const u64 w = (n_chunks + RF_THREADS - 1) / RF_THREADS;
+    const u64 rounds_l = (w + 2 * cus - 1) / (2 * cus), rounds_s = (w + 3 * cus - 1) / (3 * cus);
+    return 3 * rounds_s < 2 * rounds_l;
+}
+
 void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
     // literal form: only without a pre-shift, and for the one (MSH, r) pair that is instantiated
     const int msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : 0;
-#define RF_LAUNCH_ENC(CHECK, MSH)                                                                              \
-    hipLaunchKernelGGL((rans_encode_fast_kernel<CHECK, MSH, (MSH ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
-                       d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,  \
-                       d_status)
+    const bool slots = rf_use_slot_writer(m, n_chunks);
+#define RF_LAUNCH_ENC_W(OUT, CHECK, MSH)                                                                             \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, (MSH ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, \
+                       st, m->fdev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off,    \
+                       d_nbits, d_status)
+#define RF_LAUNCH_ENC(CHECK, MSH)                 \
+    do {                                          \
+        if (slots)                                \
+            RF_LAUNCH_ENC_W(EncOutS, CHECK, MSH); \
+        else                                      \
+            RF_LAUNCH_ENC_W(EncOutL, CHECK, MSH); \
+    } while (0)
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
     if (m->fdev.K <= 128) {
         if (msh == 10) RF_LAUNCH_ENC(1, 10); else RF_LAUNCH_ENC(1, 0);
@@ -578,6 +617,7 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
         if (msh == 10) RF_LAUNCH_ENC(false, 10); else RF_LAUNCH_ENC(false, 0);
     }
 #undef RF_LAUNCH_ENC
+#undef RF_LAUNCH_ENC_W
 }
 
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,

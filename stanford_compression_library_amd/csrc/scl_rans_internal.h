@@ -22,8 +22,8 @@ struct RansFastDev {
     u32 m_log2;     // log2(M) if M is a power of two, else 0xFFFFFFFF
     u32 L;
     u32 M;
-    u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 (rans_fast_build_tables)
-    const uint4 *d_enc_tab;  // [256] {rcp, thresh, cum, (M-f) | (k0+1) << 24}
+    u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 | r << 16 (rans_fast_build_tables)
+    const uint4 *d_enc_tab;  // [256] {rcp, (M-f) | k_lo << 24, cum, 0}
     const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
 
@@ -55,6 +55,7 @@ struct scl_rans_model {
     u32 max_bits_per_symbol;
     u32 state32;  // H < 2^32
     u32 fast;
+    u32 enc_lockstep;  // most symbols always release the same number of bits: lanes run in lockstep (writer choice)
     u32 *d_freq;
     u32 *d_cum;
     uint4 *d_enc_tab;

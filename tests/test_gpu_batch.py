@@ -382,6 +382,45 @@ def test_config2_roundtrip_properties(table, dev):
     assert abs(got - h) < 0.05, (got, h)
 
 
+def test_rans_slot_writer_batch(dev):
+    """196 608 chunks = 768 workgroups: the batch shape for which the encoder picks its three-workgroups-per-CU form
+    (AnsBackWriterS, 192-byte slot rings; rf_use_slot_writer in scl_rans_fast.hip).  Every chunk round-trips, and the
+    streams equal those of the any-parameter kernel word for word (which the goldens pin)."""
+    freq = bench_data.t256_table()
+    n_chunks, chunk_len = 196608, 4096
+    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=77, device=dev)
+    enc = model.encode_batch(sym)
+    ref = model.encode_batch(sym, any_parameter_kernels=True)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    assert torch.equal(dec, sym) and torch.equal(used, enc.nbits) and torch.equal(enc.nbits, ref.nbits)
+    assert enc.stride == ref.stride
+    # streams end at their slot end: compare the last whole words of every slot
+    nwords = int((ref.nbits.max().item() + 31) // 32)
+    a = enc.data[:n_chunks * enc.stride].view(n_chunks, enc.stride)[:, enc.stride - 4 * nwords:].contiguous().view(torch.int32)
+    b = ref.data[:n_chunks * ref.stride].view(n_chunks, ref.stride)[:, ref.stride - 4 * nwords:].contiguous().view(torch.int32)
+    col = torch.arange(a.shape[1], device=dev)[None, :]
+    assert int(((a != b) & (col >= nwords - (ref.nbits.to(torch.int64)[:, None] // 32))).sum()) == 0
+    _check_sample_against_oracle(enc, [0, 1, 777, n_chunks - 1], lambda row: orc.rans_encode(row, freq),
+                                 [sym[c].cpu().numpy() for c in [0, 1, 777, n_chunks - 1]])
+
+
+def test_rans_tests_with_slot_writer_forced():
+    """every rANS test of this file and the rANS goldens once more with SCL_RANS_ENC_WRITER=S: small, ragged and
+    odd-alphabet batches through the slot-ring writer (the variable is read once per process, hence the subprocess)"""
+    import subprocess, sys
+    env = dict(os.environ, SCL_RANS_ENC_WRITER="S")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_batch.py"),
+                        os.path.join(here, "test_gpu_goldens.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "rans and not slot_writer and not full_occupancy", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def _check_sample_against_oracle(enc, sample, o_enc, sym_rows):
     offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
     for c, row in zip(sample, sym_rows):

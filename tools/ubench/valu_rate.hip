@@ -16,6 +16,7 @@ typedef unsigned long long u64;
         for (int i = 0; i < ITERS; ++i) {                                      \
             _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) {               \
                 u32 x = v[c];                                                  \
+                unsigned long long xx = x;                                     \
                 body;                                                          \
                 v[c] = x;                                                      \
             }                                                                  \
@@ -59,6 +60,9 @@ KERNEL(mac_f32, asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x) : "v"(b)))
 KERNEL(add_e64, asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(x) : "v"(b)))
 KERNEL(add_sgpr, asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(b0)))
 KERNEL(add_const, asm volatile("v_add_u32 %0, 17, %0" : "+v"(x)))
+KERNEL(mad_u64_u32, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(xx) : "v"(b), "v"(b2) : "vcc"); x = (u32)xx)
+KERNEL(lshl_b64, asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(xx) : "v"(b)); x = (u32)xx)
+KERNEL(mul_u32_u24, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(b)))
 KERNEL(sub_co, asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(b) : "vcc"))
 
 static int g_waves = 8;
@@ -116,6 +120,6 @@ int main(int argc, char **argv) {
     RUN(cvt_f32_u32) RUN(lshl_add) RUN(bfe) RUN(sdwa_shl) RUN(mov_dpp) RUN(ffbh) RUN(sub_co)
     RUN(and_b32) RUN(or_b32) RUN(xor_b32) RUN(lshlrev) RUN(lshrrev) RUN(ashrrev) RUN(sub_u32) RUN(subrev_u32) RUN(min_u32)
     RUN(mov) RUN(cndmask) RUN(add3) RUN(and_or) RUN(lshl_or) RUN(perm) RUN(add_co) RUN(fma_f32) RUN(mac_f32) RUN(add_e64)
-    RUN(add_sgpr) RUN(add_const) RUN(add)
+    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24)
     return 0;
 }
