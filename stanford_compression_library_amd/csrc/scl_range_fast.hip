@@ -132,11 +132,14 @@ struct RgOut {
 struct RgDivM {
     u32 m_log2;
     u32 k;
+    u32 t;  // MODE 2: log2 of the common frequency
     double inv_m;
 };
-template <bool GEN>
+// MODE: 0 = power-of-two total, 1 = any total, 2 = power-of-two total shared evenly by 256 symbols (f = 2^t, c = s f:
+// no table at all -- configs[2], uniform bytes with f = 1, is the t = 0 case)
+template <int MODE>
 __device__ __forceinline__ u32 rg_range_over_m(u32 range, const RgDivM &md) {
-    if (GEN) return (u32)(((double)range + 0.5) * md.inv_m);
+    if (MODE == 1) return (u32)(((double)range + 0.5) * md.inv_m);
     return range >> md.m_log2;
 }
 
@@ -150,12 +153,18 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
 // shrink_range (:88-105) + normalize (:107-179) for one symbol; returns the first (up to four) released bytes.
 // A symbol releases at most PRECISION/8 = 4 bytes in practice; callers still run rg_needs_byte afterwards so a
 // fifth byte could never be lost.
-template <bool GEN>
+template <int MODE>
 __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, const RgDivM &md, u32 &bytes,
                                                  u32 &nb) {
-    const u32 r = rg_range_over_m<GEN>(range, md);
-    low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
-    range = r * e.y;
+    const u32 r = rg_range_over_m<MODE>(range, md);
+    if (MODE == 2) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
+        const u32 rf = r << md.t;
+        low = __umul24(e.x, rf) + low;
+        range = rf;
+    } else {
+        low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
+        range = r * e.y;
+    }
     // normalize in closed form: the loop first releases every leading byte on which low and low + range agree
     // (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them; it goes on only if
     // the range left after that is below BOTTOM (the carry-less reset, :136-178) -- rare, and handled by the
@@ -192,7 +201,14 @@ struct RgLine128 {
     }
 };
 
-template <bool GEN>
+// table entry {c, f} of the symbol whose byte offset into the table is a (= symbol * 8); MODE 2 has no table
+template <int MODE>
+__device__ __forceinline__ uint2 rg_entry(const char *tab, u32 a) {
+    if (MODE == 2) return make_uint2(a >> 3, 0u);
+    return *reinterpret_cast<const uint2 *>(tab + a);
+}
+
+template <int MODE>
 __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range, RgOut &o, u32 &bad, char *lds,
                                             const char *tab, const RgDivM &md) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
@@ -207,7 +223,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
         for (int j = 0; j < 4; j += 2) {
             bad = max(bad, max(a[j], a[j + 1]));
             u32 b0, n0, b1, n1;
-            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j]), md, b0, n0);
+            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0);
             if (n0 == 4) {  // rare: a full word at once; keep the reference's order of events
                 o.put_bytes(lds, b0, 4);
                 b0 = 0;
@@ -218,7 +234,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
                     range <<= 8;
                 }
             }
-            rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a[j + 1]), md, b1, n1);
+            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1);
             if (__builtin_expect(n0 + n1 <= 4 && n1 != 4, 1)) {
                 o.put_bytes(lds, b0 | (b1 << (8 * n0)), n0 + n1);  // n0 <= 3 here
             } else {
@@ -235,7 +251,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
     o.maybe_flush(lds);
 }
 
-template <bool GEN>
+template <int MODE>
 __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(RangeFastDev P, const u8 *__restrict__ sym,
                                                                           u64 sym_stride,
                                                                           const u32 *__restrict__ lens, u32 chunk_len,
@@ -259,6 +275,7 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     RgDivM md;
     md.m_log2 = P.m_log2;
     md.k = P.K;
+    md.t = P.uni_t;
     md.inv_m = 1.0 / (double)P.M;
 
     const u32 n_lines = n >> 7;
@@ -269,20 +286,20 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
         cur.load(src16 + 8 * t);
 #pragma nounroll
         for (int q = 0; q < 4; ++q) {
-            rg_encode16<GEN>(cur.v[0], low, range, o, bad, lds, tab, md);
-            rg_encode16<GEN>(cur.v[1], low, range, o, bad, lds, tab, md);
+            rg_encode16<MODE>(cur.v[0], low, range, o, bad, lds, tab, md);
+            rg_encode16<MODE>(cur.v[1], low, range, o, bad, lds, tab, md);
 #pragma unroll
             for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
         }
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16)
-        rg_encode16<GEN>(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, md);
+        rg_encode16<MODE>(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, md);
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 3;
         bad = max(bad, a);
         u32 bytes, nb;
-        rg_encode_symbol<GEN>(low, range, *reinterpret_cast<const uint2 *>(tab + a), md, bytes, nb);
+        rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a), md, bytes, nb);
         o.put_bytes(lds, bytes, nb);
         while (nb == 4 && rg_needs_byte(low, range)) {
             o.put_bytes(lds, low >> 24, 1);
@@ -401,18 +418,33 @@ __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
     return (u32)(((double)d + 0.5) * x);
 }
 
+// The same quotient for totals >= 256 in binary32: then r = range // M < 2^24 converts exactly and q = d // r <= M <=
+// 2^16, so fl(fl(d) * fl(1/r)) is within q 2^-22 < 2^-6 of d / r (three roundings of 2^-24, 2^-23, 2^-24); biased down
+// by 2^-5 inside the FMA it lies in (d/r - 0.047, d/r - 0.015), i.e. its floor is q or q - 1 (0 for a negative value:
+// v_cvt_u32_f32 clamps), and one remainder test settles which: 9 instructions, none of them binary64 (the ten
+// above cost ~24 ns per wave on a SIMD, these ~16: tools/ubench/valu_rate.hip).
+__device__ __forceinline__ u32 rg_div32(u32 d, u32 r) {
+    const float qf = __builtin_fmaf((float)d, __builtin_amdgcn_rcpf((float)r), -0.03125f);
+    u32 q = (u32)qf;                      // q or q - 1
+    const u32 rem = d - __umul24(q, r);   // q < 2^17, r < 2^24; rem in [0, 2r)
+    return q + (rem >= r ? 1u : 0u);
+}
+
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
 // LUT: totals up to 4096 find the symbol in a slot -> symbol table; larger ones (up to BOTTOM = 2^16) by an 8-step
 // binary search on the cumulative counts (K = alphabet size rides in md.k)
-template <bool GEN, bool LUT>
+template <int MODE, bool LUT, bool DIV32>
 __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
                                                 const RgDivM &md, u32 slot_max) {
-    const u32 rr = rg_range_over_m<GEN>(range, md);
-    u32 q = rg_div(state - low, rr);
+    const u32 rr = rg_range_over_m<MODE>(range, md);
+    u32 q = DIV32 ? rg_div32(state - low, rr) : rg_div(state - low, rr);
     q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
     u32 s;
     uint2 e;
-    if (LUT) {  // one read: slot -> {c | s << 24, f}
+    if (MODE == 2) {  // the slot IS the symbol (times f): no table read on the serial chain
+        s = q >> md.t;
+        e = make_uint2(0u, 0u);
+    } else if (LUT) {  // one read: slot -> {c | s << 24, f}
         e = *reinterpret_cast<const uint2 *>(tab + q * 8);
         s = e.x >> 24;
         e.x &= 0xFFFFFFu;
@@ -426,8 +458,14 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         }
         e = *reinterpret_cast<const uint2 *>(tab + s * 8);
     }
-    low += e.x * rr;
-    range = rr * e.y;
+    if (MODE == 2) {
+        const u32 rf = rr << md.t;  // < 2^24, see rg_encode_symbol
+        low = __umul24(s, rf) + low;
+        range = rf;
+    } else {
+        low += e.x * rr;
+        range = rr * e.y;
+    }
     const u32 lk = r.look();
     u32 nb = 0;
     // closed form of the common case, see rg_encode_symbol
@@ -461,10 +499,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     return s;
 }
 
-// (the 144 bytes of private segment this kernel reports are the `a[8]` line accumulator below, which the compiler keeps
-// as an indexed stack array because it declines to unroll the 16-symbol body eight times -- eight 16-byte scratch
-// stores and loads per 128 symbols, not register spills)
-template <bool GEN, bool LUT>
+template <int MODE, bool LUT, bool DIV32>
 __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,
                                                                        const u64 *__restrict__ bit_off,
@@ -514,6 +549,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     RgDivM md;
     md.m_log2 = P.m_log2;
     md.k = P.K;
+    md.t = P.uni_t;
     md.inv_m = 1.0 / (double)P.M;
 
     u32 i = 0;
@@ -532,7 +568,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                 u32 o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32 s = rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, md, slot_max);
+                    const u32 s = rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
                     o |= s << (8 * j);
                 }
                 r.maybe_refill(lds);
@@ -546,7 +582,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         for (int b = 0; b < 8; ++b) p[b] = a[b];
     }
     for (; i < n; ++i) {  // ragged tail
-        dst[i] = (u8)rg_decode_symbol<GEN, LUT>(low, range, state, r, lds, tab, md, slot_max);
+        dst[i] = (u8)rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
         if ((i & 3u) == 3u) r.maybe_refill(lds);
     }
     const u32 used_bits = r.consumed();
@@ -578,6 +614,12 @@ int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_
     m->fdev.K = D.K;
     m->fdev.m_log2 = D.m_log2;
     m->fdev.M = D.M;
+    m->fdev.uni_t = 0xFFFFFFFFu;
+    if (D.K == 256 && D.m_log2 != 0xFFFFFFFFu && D.m_log2 >= 8) {
+        bool same = true;
+        for (u32 s = 1; s < 256; ++s) same = same && h_freq[s] == h_freq[0];
+        if (same) m->fdev.uni_t = D.m_log2 - 8;  // f = M / 256
+    }
     m->fdev.d_enc_tab = m->d_enc_tab;
     m->fdev.d_slot2sym = m->d_slot2sym;
     m->fast = 1;
@@ -588,26 +630,36 @@ void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym
                               u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                               u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RGE_THREADS - 1) / RGE_THREADS);
-    if (m->fdev.m_log2 != 0xFFFFFFFFu)
-        hipLaunchKernelGGL(range_encode_fast_kernel<false>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,
-                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
-    else
-        hipLaunchKernelGGL(range_encode_fast_kernel<true>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,
-                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status);
+#define RG_LAUNCH_ENC(MODE)                                                                                      \
+    hipLaunchKernelGGL(range_encode_fast_kernel<MODE>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,       \
+                       sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
+    if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_ENC(2);
+    else if (m->fdev.m_log2 != 0xFFFFFFFFu) RG_LAUNCH_ENC(0);
+    else RG_LAUNCH_ENC(1);
+#undef RG_LAUNCH_ENC
 }
 
 void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RGD_THREADS - 1) / RGD_THREADS);
-#define RG_LAUNCH_DEC(GEN, LUT)                                                                                  \
-    hipLaunchKernelGGL((range_decode_fast_kernel<GEN, LUT>), dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, d_in, \
+#define RG_LAUNCH_DEC2(MODE, LUT, DIV32)                                                                          \
+    hipLaunchKernelGGL((range_decode_fast_kernel<MODE, LUT, DIV32>), dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, \
+                       d_in,                                                                                      \
                        in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,   \
                        d_consumed, d_status)
+    // totals of 256 and more divide in binary32 (rg_div32)
+#define RG_LAUNCH_DEC(MODE, LUT)                                       \
+    do {                                                               \
+        if (m->fdev.M >= 256) RG_LAUNCH_DEC2(MODE, LUT, true);         \
+        else RG_LAUNCH_DEC2(MODE, LUT, false);                         \
+    } while (0)
     const bool pow2 = m->fdev.m_log2 != 0xFFFFFFFFu, lut = m->fdev.M <= 4096;
-    if (pow2 && lut) RG_LAUNCH_DEC(false, true);
-    else if (pow2) RG_LAUNCH_DEC(false, false);
-    else if (lut) RG_LAUNCH_DEC(true, true);
-    else RG_LAUNCH_DEC(true, false);
+    if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_DEC2(2, true, true);
+    else if (pow2 && lut) RG_LAUNCH_DEC(0, true);
+    else if (pow2) RG_LAUNCH_DEC(0, false);
+    else if (lut) RG_LAUNCH_DEC(1, true);
+    else RG_LAUNCH_DEC(1, false);
 #undef RG_LAUNCH_DEC
+#undef RG_LAUNCH_DEC2
 }

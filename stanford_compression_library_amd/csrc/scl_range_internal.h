@@ -19,6 +19,8 @@ struct RangeFastDev {
     u32 K;
     u32 m_log2;  // log2(M) if power of two else 0xFFFFFFFF
     u32 M;
+    u32 uni_t;   // 256 symbols of one power-of-two frequency 2^uni_t (total a power of two): the table-free kernels;
+                 // 0xFFFFFFFF otherwise
     const uint2 *d_enc_tab;  // [256] {cum, freq}
     const u8 *d_slot2sym;    // [M]
 };

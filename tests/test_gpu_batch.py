@@ -432,6 +432,40 @@ def _check_sample_against_oracle(enc, sample, o_enc, sym_rows):
         assert np.array_equal(bits, np.unpackbits(rb)[:rn]), f"chunk {c}"
 
 
+@pytest.mark.parametrize("f", [1, 2, 16, 256])
+def test_range_uniform_table_kernels_vs_oracle(f, dev):
+    """256 symbols of one power-of-two frequency (total 256 f, up to BOTTOM = 2^16): the table-free range-coder kernels
+    (MODE 2 in scl_range_fast.hip; configs[2] is f = 1).  Ragged batch against the oracle, bit for bit."""
+    freq = np.full(256, f, dtype=np.int64)
+    rng = np.random.default_rng(300 + f)
+    lens = [0, 1, 2, 3, 15, 16, 17, 127, 128, 129, 1000, 4096, 4097] + [int(x) for x in rng.integers(1, 3000, 19)]
+    rows = [rng.integers(0, 256, n).astype(np.uint8) for n in lens]
+    # a few rows that hug the ends of the alphabet (carry-less resets, long runs of equal bytes)
+    rows += [np.zeros(777, np.uint8), np.full(777, 255, np.uint8), np.tile(np.array([255, 0], np.uint8), 400)]
+    model = models.RangeModel(freq.tolist(), 32, 32)
+    assert model.fast_path()
+    cap = max(len(r) for r in rows)
+    sym = np.zeros((len(rows), (cap + 15) // 16 * 16), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        sym[i, :len(r)] = r
+    lens_t = torch.tensor([len(r) for r in rows], dtype=torch.int32, device=dev)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=lens_t)
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec_h, dl = dec.cpu().numpy(), dlens.cpu().numpy()
+    for i, r in enumerate(rows):
+        rb, rn = orc.range_encode(r, freq)
+        assert int(nbits[i]) == rn, (i, len(r))
+        lo = int(offs[i]) // 8
+        window = enc.data[lo:lo + (rn + 7) // 8 + 2].cpu().numpy()
+        bits = np.unpackbits(window)[int(offs[i]) % 8:][:rn]
+        assert np.array_equal(bits, np.unpackbits(rb)[:rn]), (i, len(r))
+        assert int(dl[i]) == len(r) and np.array_equal(dec_h[i, :len(r)], r), (i, len(r))
+    assert torch.equal(used, enc.nbits)
+
+
 def test_config3_range_coder_full_size_properties(dev):
     """BASELINE.json configs[2]: 32-bit range coder on 1 GiB of uniform bytes (f = 1, M = 256), 262 144 chunks of
     4 KiB.  decode(encode(x)) == x for every chunk, consumed == produced, every stream is the 32-bit header plus

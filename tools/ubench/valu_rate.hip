@@ -17,6 +17,8 @@ typedef unsigned long long u64;
             _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) {               \
                 u32 x = v[c];                                                  \
                 unsigned long long xx = x;                                     \
+                double dd = __longlong_as_double(0x3ff0000000000000ull | x);   \
+                double db = 1.0000001;                                         \
                 body;                                                          \
                 v[c] = x;                                                      \
             }                                                                  \
@@ -63,6 +65,13 @@ KERNEL(add_const, asm volatile("v_add_u32 %0, 17, %0" : "+v"(x)))
 KERNEL(mad_u64_u32, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(xx) : "v"(b), "v"(b2) : "vcc"); x = (u32)xx)
 KERNEL(lshl_b64, asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(xx) : "v"(b)); x = (u32)xx)
 KERNEL(mul_u32_u24, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(b)))
+KERNEL(fma_f64, asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(dd) : "v"(db)); x = (u32)__double_as_longlong(dd))
+KERNEL(mul_f64, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd) : "v"(db)); x = (u32)__double_as_longlong(dd))
+KERNEL(add_f64, asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd) : "v"(db)); x = (u32)__double_as_longlong(dd))
+KERNEL(cvt_f64_u32, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(dd) : "v"(x)); x = (u32)__double_as_longlong(dd))
+KERNEL(cvt_u32_f64, asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(x) : "v"(dd)))
+KERNEL(rcp_f32, asm volatile("v_rcp_f32 %0, %0" : "+v"(x)))
+KERNEL(cvt_u32_f32, asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(x)))
 KERNEL(sub_co, asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(b) : "vcc"))
 
 static int g_waves = 8;
@@ -120,6 +129,6 @@ int main(int argc, char **argv) {
     RUN(cvt_f32_u32) RUN(lshl_add) RUN(bfe) RUN(sdwa_shl) RUN(mov_dpp) RUN(ffbh) RUN(sub_co)
     RUN(and_b32) RUN(or_b32) RUN(xor_b32) RUN(lshlrev) RUN(lshrrev) RUN(ashrrev) RUN(sub_u32) RUN(subrev_u32) RUN(min_u32)
     RUN(mov) RUN(cndmask) RUN(add3) RUN(and_or) RUN(lshl_or) RUN(perm) RUN(add_co) RUN(fma_f32) RUN(mac_f32) RUN(add_e64)
-    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24)
+    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24) RUN(fma_f64) RUN(mul_f64) RUN(add_f64) RUN(cvt_f64_u32) RUN(cvt_u32_f64) RUN(rcp_f32) RUN(cvt_u32_f32)
     return 0;
 }
