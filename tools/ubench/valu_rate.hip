@@ -19,6 +19,7 @@ typedef unsigned long long u64;
                 unsigned long long xx = x;                                     \
                 double dd = __longlong_as_double(0x3ff0000000000000ull | x);   \
                 double db = 1.0000001;                                         \
+                unsigned long long mask64 = 0x5555555555555555ull ^ b0, mask64w = 0;  \
                 body;                                                          \
                 v[c] = x;                                                      \
             }                                                                  \
@@ -72,6 +73,12 @@ KERNEL(cvt_f64_u32, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(dd) : "v"(x)); x 
 KERNEL(cvt_u32_f64, asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(x) : "v"(dd)))
 KERNEL(rcp_f32, asm volatile("v_rcp_f32 %0, %0" : "+v"(x)))
 KERNEL(cvt_u32_f32, asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(x)))
+KERNEL(cnd_vcc_dst, asm volatile("v_cndmask_b32 %1, %0, %2, vcc\n\tv_add_u32 %0, %0, %1" : "+v"(x), "+v"(tmp) : "v"(b) : "vcc"))
+KERNEL(cnd_sgpr, asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(mask64)))
+KERNEL(cnd_sgpr_dst, asm volatile("v_cndmask_b32_e64 %1, %0, %2, %3\n\tv_add_u32 %0, %0, %1" : "+v"(x), "+v"(tmp) : "v"(b), "s"(mask64)))
+KERNEL(cmp_only, asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc"); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b)))
+KERNEL(cmp_cnd, asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc"))
+KERNEL(cmp_cnd_sgpr, asm volatile("v_cmp_lt_u32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x), "+v"(b) , "+s"(mask64w)))
 KERNEL(sub_co, asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(b) : "vcc"))
 
 static int g_waves = 8;
@@ -129,6 +136,6 @@ int main(int argc, char **argv) {
     RUN(cvt_f32_u32) RUN(lshl_add) RUN(bfe) RUN(sdwa_shl) RUN(mov_dpp) RUN(ffbh) RUN(sub_co)
     RUN(and_b32) RUN(or_b32) RUN(xor_b32) RUN(lshlrev) RUN(lshrrev) RUN(ashrrev) RUN(sub_u32) RUN(subrev_u32) RUN(min_u32)
     RUN(mov) RUN(cndmask) RUN(add3) RUN(and_or) RUN(lshl_or) RUN(perm) RUN(add_co) RUN(fma_f32) RUN(mac_f32) RUN(add_e64)
-    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24) RUN(fma_f64) RUN(mul_f64) RUN(add_f64) RUN(cvt_f64_u32) RUN(cvt_u32_f64) RUN(rcp_f32) RUN(cvt_u32_f32)
+    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24) RUN(fma_f64) RUN(mul_f64) RUN(add_f64) RUN(cvt_f64_u32) RUN(cvt_u32_f64) RUN(rcp_f32) RUN(cvt_u32_f32) RUN(cndmask) RUN(cnd_vcc_dst) RUN(cnd_sgpr) RUN(cnd_sgpr_dst) RUN(cmp_only) RUN(cmp_cnd) RUN(cmp_cnd_sgpr)
     return 0;
 }
