@@ -5,16 +5,18 @@
 // what changes is how a lane spends its instructions:
 //
 //  encode, per symbol (one 16-byte LDS table read, issued one word = four symbols ahead of its use):
-//    k     = k0[s] + (x >= thresh[s])                    closed form of shrink_state's while-loop
+//    k     = k_lo[s] + (x >= thresh[s])                  closed form of shrink_state's while-loop
 //                                                         (rANS.py:149-161; tANS.py:74-86 gives the same rule)
 //    field = low k bits of x;  xs = x >> k
-//    q     = floor(xs / f) = mulhi(x << (32-nsb), rcp[s]) >> (s[s] + k),  s[s] + k0[s] == m
+//    q     = floor(xs / f) = mulhi(x << (32-nsb), rcp[s]) >> (s[s] + k),  s[s] + k_lo[s] == m
 //            with rcp = ceil(2^(nsb+s) / f), s = ceil(log2 f): exact for every x < 2^nsb
 //            (error term x*e/(f*2^(nsb+s+k)) < 2^-(s+k) <= 1/(f*2^k))
+//            -- and the threshold test is read off the same product: q0 = floor(x / (f 2^k_lo)) >= 2 RF  <=>  x >= thresh
 //    x     = xs + c[s] + q*(M - f[s])                     == (xs//f)*M + c + xs%f  (rANS.py:138-147)
 //    The field is never extracted: v_alignbit shifts the low k bits of x straight into a 64-bit bit window; completed
-//    big-endian words go to a 64-word per-lane LDS ring and leave as whole 128-byte lines, back to front, stored by the
-//    four lanes of the source lane's quad (AnsBackWriterL, scl_ans_fast_io.h).
+//    big-endian words go to a per-lane LDS ring and leave as whole 128-byte lines, back to front, stored by the four
+//    lanes of the source lane's quad (AnsBackWriterL: 64-word rings, two workgroups per CU; AnsBackWriterS: 48-word
+//    rings in 64-byte slots, three workgroups per CU, taken when that saves a round of workgroups; scl_ans_fast_io.h).
 //  decode, per symbol (one 8-byte LDS table read, slot -> {f | sym << 24, slot - c}):
 //    x  = (x >> m)*f + (slot - c)                          rans_base_decode_step (rANS.py:234-249)
 //    nb = clz(x) - (32 - nsb);  x = (x << nb) | next nb bits   closed form of expand_state (:251-260),
