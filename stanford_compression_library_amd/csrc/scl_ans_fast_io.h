@@ -232,23 +232,51 @@ struct AnsBackWriterL {
     // account for the `bits` (<= 26) pushed since the last call.  The subtraction's borrow IS the test "33 or more bits
     // pending" (v_sub_co_u32 + a branch on VCC: no separate compare); the wrapped counter's low 5 bits are the shift that
     // brings the oldest 32 bits down: (32 - n) mod 32 = 64 - n for 33 <= n <= 63.
+    // RING_OFF: byte offset of the rings in the workgroup's LDS block (an immediate of the ds_write).  The block is
+    // written by hand: the compiler's version of the same seven instructions carries an s_cbranch_execz that skips them
+    // when no lane completed a word -- practically never, with 64 lanes -- and every instruction on this path, which the
+    // whole wave runs for every pair of symbols, is ~2.5 % of the kernel (0.575 -> 0.556 ms).  LDS instructions of a wave
+    // execute in order, so the flush rounds' reads see these writes; the compiler, which does not know of them, can only
+    // wait too long for its own LDS operations, never too short.
+    template <u32 RING_OFF>
     __device__ __forceinline__ void check(char *lds, u32 bits) {
+#ifndef RF_NO_ASM_CHECK
+        u32 w, t;
+        u64 sv;
+        asm volatile(
+            "v_sub_co_u32 %[room], vcc, %[room], %[bits]\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "v_alignbit_b32 %[w], %[hi], %[lo], %[room]\n\t"
+            "v_add_u32 %[t], 0xfc, %[wa]\n\t"
+            "v_perm_b32 %[w], 0, %[w], %[sel]\n\t"
+            "v_add_u32 %[room], 32, %[room]\n\t"
+            "ds_write_b32 %[wa], %[w] offset:%[off]\n\t"
+            "v_and_or_b32 %[wa], %[t], %[m255], %[base]\n\t"
+            "s_or_b64 exec, exec, %[sv]"
+            : [room] "+v"(room), [wa] "+v"(wa), [w] "=&v"(w), [t] "=&v"(t), [sv] "=&s"(sv)
+            : [bits] "v"(bits), [hi] "v"(hi), [lo] "v"(lo), [sel] "s"(0x00010203u), [m255] "s"(255u), [base] "v"(base),
+              [off] "i"(RING_OFF)
+            : "vcc", "memory");
+        (void)lds;
+#else
         if (__builtin_usub_overflow(room, bits, &room)) {
             const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
             *reinterpret_cast<u32 *>(lds + wa) = __builtin_bswap32(word);
             wa = ((wa - 4u) & 255u) | base;  // one v_add + one v_and_or: the address register is the only state
             room += 32;
         }
+#endif
     }
+    template <u32 RING_OFF>
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
         if (w > 16) {
             push(v, 16);
-            check(lds, 16);
+            check<RING_OFF>(lds, 16);
             push(v >> 16, w - 16);
-            check(lds, w - 16);
+            check<RING_OFF>(lds, w - 16);
         } else {
             push(v, w);
-            check(lds, w);
+            check<RING_OFF>(lds, w);
         }
     }
     template <int R>
@@ -361,7 +389,27 @@ struct AnsBackWriterS {
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
         hi = __builtin_amdgcn_alignbit(v, hi, k);
     }
-    __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check
+    template <u32 RING_OFF>
+    __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check, by hand for the same reason
+#ifndef RF_NO_ASM_CHECK
+        u32 w, t;
+        u64 sv;
+        asm volatile(
+            "v_sub_co_u32 %[room], vcc, %[room], %[bits]\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "v_alignbit_b32 %[w], %[hi], %[lo], %[room]\n\t"
+            "v_add_u32 %[t], %[base], %[wo]\n\t"
+            "v_perm_b32 %[w], 0, %[w], %[sel]\n\t"
+            "v_add_u32 %[wo], -4, %[wo]\n\t"
+            "ds_write_b32 %[t], %[w] offset:%[off]\n\t"
+            "v_min_u32 %[wo], 0xbc, %[wo]\n\t"  // (wo - 4) mod 192: only wo == 0 wraps, to a huge unsigned value
+            "v_add_u32 %[room], 32, %[room]\n\t"
+            "s_or_b64 exec, exec, %[sv]"
+            : [room] "+v"(room), [wo] "+v"(wo), [w] "=&v"(w), [t] "=&v"(t), [sv] "=&s"(sv)
+            : [bits] "v"(bits), [hi] "v"(hi), [lo] "v"(lo), [sel] "s"(0x00010203u), [base] "v"(base), [off] "i"(RING_OFF)
+            : "vcc", "memory");
+        (void)lds;
+#else
         if (__builtin_usub_overflow(room, bits, &room)) {
             const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
             *reinterpret_cast<u32 *>(lds + (base + wo)) = __builtin_bswap32(word);
@@ -370,16 +418,18 @@ struct AnsBackWriterS {
             wo = min(wo - 4u, LANE_BYTES - 4u);
             room += 32;
         }
+#endif
     }
+    template <u32 RING_OFF>
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
         if (w > 16) {
             push(v, 16);
-            check(lds, 16);
+            check<RING_OFF>(lds, 16);
             push(v >> 16, w - 16);
-            check(lds, w - 16);
+            check<RING_OFF>(lds, w - 16);
         } else {
             push(v, w);
-            check(lds, w);
+            check<RING_OFF>(lds, w);
         }
     }
     template <int R>

@@ -55,6 +55,7 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 // Two writers (scl_ans_fast_io.h): AnsBackWriterL, 256-byte rings, two workgroups per CU; AnsBackWriterS, 192-byte
 // rings in 64-byte slots, three workgroups per CU -- for batches that can populate a third wave per SIMD
 // (rans_fast_encode_launch).
+#define RF_RING_OFF 4096u  // the rings sit behind the 4 KiB symbol table in the workgroup's LDS block
 typedef AnsBackWriterL<RF_THREADS> EncOutL;
 typedef AnsBackWriterS<RF_THREADS> EncOutS;
 
@@ -150,10 +151,10 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
         }
         const u32 k0 = rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o);
         const u32 k1 = rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o);
-        o.check(lds, k0 + k1);
+        o.template check<RF_RING_OFF>(lds, k0 + k1);
         const u32 k2 = rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o);
         const u32 k3 = rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o);
-        o.check(lds, k2 + k3);
+        o.template check<RF_RING_OFF>(lds, k2 + k3);
     }
 }
 
@@ -170,20 +171,14 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
                                                                         u32 *__restrict__ status) {
     // one LDS block: the 4 KiB symbol table first (its offsets then fit the 16-bit offset field of the DS instructions;
     // behind the rings, every table address cost an extra VALU instruction), then 64 KiB of word rings
-#ifndef RF_TAB_COPIES
-#define RF_TAB_COPIES 1
-#endif
 #ifndef RF_LDS_PAD
 #define RF_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
 #endif
-    __shared__ __attribute__((aligned(16))) char s_lds[RF_TAB_COPIES * 256 * 16 + EncOut::RING_BYTES + RF_LDS_PAD];
-    char *lds = s_lds + RF_TAB_COPIES * 256 * 16;
-    // RF_TAB_COPIES = 2 (experiment): odd lanes read a second copy of the table -- the 16 lanes of a ds_read_b128 pass
-    // then spread over twice the banks
-    const char *tab = s_lds + (RF_TAB_COPIES == 2 ? (threadIdx.x & 1u) * 4096u : 0u);
-#pragma unroll
-    for (int cpy = 0; cpy < RF_TAB_COPIES; ++cpy)
-        reinterpret_cast<uint4 *>(s_lds + cpy * 4096)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_RING_OFF + EncOut::RING_BYTES + RF_LDS_PAD];
+    char *lds = s_lds + RF_RING_OFF;
+    const char *tab = s_lds;
+    static_assert(RF_RING_OFF == 256 * sizeof(uint4), "the rings start right behind the symbol table");
+    reinterpret_cast<uint4 *>(s_lds)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * RF_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
@@ -272,15 +267,15 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
-        o.check(lds, rf_encode_entry<MSH_T, R_T>(x, *reinterpret_cast<const EncEntry *>(tab + a), msh_rt, o));
+        o.template check<RF_RING_OFF>(lds, rf_encode_entry<MSH_T, R_T>(x, *reinterpret_cast<const EncEntry *>(tab + a), msh_rt, o));
         if ((i & 15u) == 15u) RF_FLUSH();
     }
     RF_FLUSH();
 #undef RF_FLUSH
-    o.put32(lds, x, P.nsb);
+    o.template put32<RF_RING_OFF>(lds, x, P.nsb);
     u32 st = (CHECK_SYM && (bad & 0x80808080u)) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
-    o.put32(lds, n, P.size_bits);
+    o.template put32<RF_RING_OFF>(lds, n, P.size_bits);
     const u64 total = o.finish(lds, wg_out);
     out_bit_off[c] = (c + 1) * out_stride * 8 - total;
     out_nbits[c] = (u32)total;
