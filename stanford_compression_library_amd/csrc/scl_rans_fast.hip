@@ -67,21 +67,18 @@ __device__ __forceinline__ u32 rf_mad24(u32 a, u32 b, u32 c) {
     return d;
 }
 
-// One symbol.  Table entry {rcp, (M-f) | k_lo << 24, c, 0}.
+// One symbol.  Table entry {rcp, M-f, c, k_lo}.
 // MSH = m - (32 - nsb) + 1 as before; q0 = mulhi(x, rcp) >> (MSH - 1) = floor(x / (f 2^k_lo)) is exact for EVERY
 // x < 2^nsb (rans_fast_build_tables), so the test "x >= thresh = 2 RF f 2^k_lo" is simply q0 >= 2 RF: no threshold in
 // the table, no subtraction -- pos = q0 >> (r + 1) (q0 < 4 RF), k = k_lo + pos, q = floor((x >> k) / f) = q0 >> pos
 // (nested floors).  The k released bits are never extracted: push() takes the low k bits of x by itself.
 struct __attribute__((aligned(16))) EncEntry {
-    u32 rcp, mfk, c, pad;
+    u32 rcp, mf, c, k_lo;  // all four words in use: the read stays a ds_read_b128 (a ds_read_b96 is far slower here)
 };
 template <int MSH_T, int R_T, typename EncOut>
 __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns k
     // run-time form: msh_rt = MSH | pre << 8 | r << 16.  Tables so small that m < 32 - nsb would need a negative MSH;
     // they shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
-    // keep the table read a ds_read_b128: the compiler would shrink it to the 12 bytes in use, and ds_read_b96 is far
-    // slower on this chip (whole kernel 0.58 -> 0.68 ms)
-    asm volatile("" : : "v"(e.pad));
     const u32 mh = rf_umulhi(MSH_T ? x : (x << ((msh_rt >> 8) & 0xFFu)), e.rcp);
     u32 q0, pos;
     if (MSH_T) {
@@ -92,9 +89,9 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh
         q0 = mh >> ((msh_rt & 0xFFu) - 1u);
         pos = q0 >> ((msh_rt >> 16) + 1u);
     }
-    const u32 k = (e.mfk >> 24) + pos;
+    const u32 k = e.k_lo + pos;  // a plain add: a byte of another word would cost an SDWA form, 1.75 instead of 1.05 ns
     o.push(x, k);
-    x = rf_mad24(q0 >> pos, e.mfk, (x >> k) + e.c);  // v_mad_u32_u24 reads only the low 24 bits of e.mfk
+    x = rf_mad24(q0 >> pos, e.mf, (x >> k) + e.c);
     return k;
 }
 
@@ -113,7 +110,7 @@ struct Entries4 {
 #define RF_LOAD_ENTRY(dst, addr)                                                \
     do {                                                                        \
         const uint2 t2 = *reinterpret_cast<const uint2 *>(tab + (addr));        \
-        dst.rcp = t2.x, dst.mfk = t2.y, dst.c = 0, dst.pad = 0;                 \
+        dst.rcp = t2.x, dst.mf = t2.y & 0xFFFFu, dst.c = 0, dst.k_lo = t2.y >> 24;                 \
     } while (0)
 #else
 #define RF_LOAD_ENTRY(dst, addr) dst = *reinterpret_cast<const EncEntry *>(tab + (addr))
@@ -531,7 +528,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
         if (E < nsb + ceil_log2_u32(f) || E > 62) return SCL_OK;  // cannot happen (see above)
         const u64 rcp = ((1ull << E) + f - 1) / f;
         if (rcp >> 32) return SCL_OK;
-        enc[s] = make_uint4((u32)rcp, (M - f) | (k_lo << 24), c, 0u);
+        enc[s] = make_uint4((u32)rcp, M - f, c, k_lo);
         if (s < D.K && k_hi == k_lo && k_lo < 32) fixed_k_mass[k_lo] += f;
     }
     // lanes whose symbols nearly all release the same number of bits complete their words at the same steps

@@ -23,7 +23,7 @@ struct RansFastDev {
     u32 L;
     u32 M;
     u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 | r << 16 (rans_fast_build_tables)
-    const uint4 *d_enc_tab;  // [256] {rcp, (M-f) | k_lo << 24, cum, 0}
+    const uint4 *d_enc_tab;  // [256] {rcp, M-f, cum, k_lo}
     const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
 
