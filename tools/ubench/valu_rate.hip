@@ -79,6 +79,10 @@ KERNEL(cnd_sgpr_dst, asm volatile("v_cndmask_b32_e64 %1, %0, %2, %3\n\tv_add_u32
 KERNEL(cmp_only, asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc"); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b)))
 KERNEL(cmp_cnd, asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc"))
 KERNEL(cmp_cnd_sgpr, asm volatile("v_cmp_lt_u32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x), "+v"(b) , "+s"(mask64w)))
+KERNEL(add_waitcnt, asm volatile("v_add_u32 %0, %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(x) : "v"(b)))
+KERNEL(add_snop, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 0" : "+v"(x) : "v"(b)))
+KERNEL(alignbit_waitcnt, asm volatile("v_alignbit_b32 %0, %0, %1, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(x) : "v"(b)))
+KERNEL(alignbit_branch, asm volatile("v_alignbit_b32 %0, %0, %1, %1\n\ts_cbranch_execz 0" : "+v"(x) : "v"(b)))
 KERNEL(sub_co, asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(b) : "vcc"))
 
 static int g_waves = 8;
@@ -120,6 +124,9 @@ int main(int argc, char **argv) {
             run("alignbit", k_alignbit, dd);
             run("mul_hi_u32", k_mul_hi_u32, dd);
             run("mix_fs(2 instr)", k_mix_fs, dd);
+            run("add + s_waitcnt", k_add_waitcnt, dd);
+            run("alignbit + s_waitcnt", k_alignbit_waitcnt, dd);
+            run("alignbit + s_cbranch", k_alignbit_branch, dd);
             run("cmp_eq+add (2)", k_cmp_eq, dd);
             run("cmp+cndmask+add (3)", k_cmp_cnd_add, dd);
             run("cndmask", k_cnd_only, dd);
@@ -136,6 +143,6 @@ int main(int argc, char **argv) {
     RUN(cvt_f32_u32) RUN(lshl_add) RUN(bfe) RUN(sdwa_shl) RUN(mov_dpp) RUN(ffbh) RUN(sub_co)
     RUN(and_b32) RUN(or_b32) RUN(xor_b32) RUN(lshlrev) RUN(lshrrev) RUN(ashrrev) RUN(sub_u32) RUN(subrev_u32) RUN(min_u32)
     RUN(mov) RUN(cndmask) RUN(add3) RUN(and_or) RUN(lshl_or) RUN(perm) RUN(add_co) RUN(fma_f32) RUN(mac_f32) RUN(add_e64)
-    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24) RUN(fma_f64) RUN(mul_f64) RUN(add_f64) RUN(cvt_f64_u32) RUN(cvt_u32_f64) RUN(rcp_f32) RUN(cvt_u32_f32) RUN(cndmask) RUN(cnd_vcc_dst) RUN(cnd_sgpr) RUN(cnd_sgpr_dst) RUN(cmp_only) RUN(cmp_cnd) RUN(cmp_cnd_sgpr)
+    RUN(add_sgpr) RUN(add_const) RUN(add) RUN(mad_u64_u32) RUN(lshl_b64) RUN(mul_u32_u24) RUN(fma_f64) RUN(mul_f64) RUN(add_f64) RUN(cvt_f64_u32) RUN(cvt_u32_f64) RUN(rcp_f32) RUN(cvt_u32_f32) RUN(cndmask) RUN(cnd_vcc_dst) RUN(cnd_sgpr) RUN(cnd_sgpr_dst) RUN(cmp_only) RUN(cmp_cnd) RUN(cmp_cnd_sgpr) RUN(add) RUN(add_waitcnt) RUN(add_snop) RUN(alignbit) RUN(alignbit_waitcnt) RUN(alignbit_branch)
     return 0;
 }
