@@ -150,46 +150,61 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
     return true;
 }
 
-// shrink_range (:88-105) + normalize (:107-179) for one symbol; returns the first (up to four) released bytes.
-// A symbol releases at most PRECISION/8 = 4 bytes in practice; callers still run rg_needs_byte afterwards so a
-// fifth byte could never be lost.
+// shrink_range (:88-105) + normalize (:107-179) for one symbol; returns its released bytes (0..3 of them, first one in
+// the low byte).  The normalisation is a closed form: the loop first releases every leading byte on which low and
+// low + range agree (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them (range > 0, so
+// the two values differ and nb1 <= 3); it goes on only if the range left after that is below BOTTOM (the carry-less
+// reset, :136-178) -- rare.  ONE branch per symbol covers everything rare: the reference's literal loop, a symbol that
+// releases a whole word (the bytes (pb, pn) its pair partner still holds go out first, to keep the reference's order of
+// events) and the bytes after a fourth.  Fast-path results are computed unconditionally and overwritten there (branches
+// are what this kernel has too many of: each costs 0.4-1.3 ns per wave, tools/ubench/valu_rate.hip).
 template <int MODE>
 __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, const RgDivM &md, u32 &bytes,
-                                                 u32 &nb) {
+                                                 u32 &nb, u32 &pb, u32 &pn, RgOut &o, char *lds) {
     const u32 r = rg_range_over_m<MODE>(range, md);
+    u32 low0, range0;
     if (MODE == 2) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
-        const u32 rf = r << md.t;
-        low = __umul24(e.x, rf) + low;
-        range = rf;
+        range0 = r << md.t;
+        low0 = __umul24(e.x, range0) + low;
     } else {
-        low += e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
-        range = r * e.y;
+        low0 = low + e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
+        range0 = r * e.y;
     }
-    // normalize in closed form: the loop first releases every leading byte on which low and low + range agree
-    // (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them; it goes on only if
-    // the range left after that is below BOTTOM (the carry-less reset, :136-178) -- rare, and handled by the
-    // literal loop.  range > 0, so the two values differ and nb1 <= 3.
-    const u32 nb1 = (u32)__builtin_clz(low ^ (low + range)) >> 3;
+    const u32 nb1 = (u32)__builtin_clz(low0 ^ (low0 + range0)) >> 3;
     const u32 sh = 8 * nb1;
-    const u32 range_s = range << sh;
-    if (__builtin_expect(range_s >= RG_BOTTOM, 1)) {
-        bytes = __builtin_bswap32(low) & ((1u << sh) - 1u);  // the released bytes, first one in the low byte
-        nb = nb1;
-        low <<= sh;
-        range = range_s;
-        return;
-    }
-    bytes = 0;
-    nb = 0;
+    const u32 range_s = range0 << sh;
+    bytes = __builtin_bswap32(low0) & ((1u << sh) - 1u);
+    nb = nb1;
+    low = low0 << sh;
+    range = range_s;
+    if (__builtin_expect(range_s < RG_BOTTOM, 0)) {
+        low = low0;
+        range = range0;
+        bytes = 0;
+        nb = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool settled = ((low ^ (low + range)) < RG_TOP);
-        if (!settled && range >= RG_BOTTOM) break;
-        if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
-        bytes |= (low >> 24) << (8 * j);
-        ++nb;
-        low <<= 8;
-        range <<= 8;
+        for (int j = 0; j < 4; ++j) {
+            const bool settled = ((low ^ (low + range)) < RG_TOP);
+            if (!settled && range >= RG_BOTTOM) break;
+            if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
+            bytes |= (low >> 24) << (8 * j);
+            ++nb;
+            low <<= 8;
+            range <<= 8;
+        }
+        if (nb == 4) {  // a whole word at once: everything goes out now, in the reference's order
+            o.put_bytes(lds, pb, pn);
+            pb = 0;
+            pn = 0;
+            o.put_bytes(lds, bytes, 4);
+            bytes = 0;
+            nb = 0;
+            while (rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
+                o.put_bytes(lds, low >> 24, 1);
+                low <<= 8;
+                range <<= 8;
+            }
+        }
     }
 }
 
@@ -222,29 +237,14 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
             bad = max(bad, max(a[j], a[j + 1]));
-            u32 b0, n0, b1, n1;
-            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0);
-            if (n0 == 4) {  // rare: a full word at once; keep the reference's order of events
-                o.put_bytes(lds, b0, 4);
-                b0 = 0;
-                n0 = 0;
-                while (rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
-                    o.put_bytes(lds, low >> 24, 1);
-                    low <<= 8;
-                    range <<= 8;
-                }
-            }
-            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1);
-            if (__builtin_expect(n0 + n1 <= 4 && n1 != 4, 1)) {
-                o.put_bytes(lds, b0 | (b1 << (8 * n0)), n0 + n1);  // n0 <= 3 here
+            u32 b0, n0, b1, n1, z0 = 0, zn = 0;
+            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0, z0, zn, o, lds);
+            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1, b0, n0, o, lds);
+            if (n0 + n1 <= 4) {  // each <= 3
+                o.put_bytes(lds, b0 | (b1 << (8 * n0)), n0 + n1);
             } else {
                 o.put_bytes(lds, b0, n0);
                 o.put_bytes(lds, b1, n1);
-                while (n1 == 4 && rg_needs_byte(low, range)) {
-                    o.put_bytes(lds, low >> 24, 1);
-                    low <<= 8;
-                    range <<= 8;
-                }
             }
         }
     }
@@ -298,14 +298,9 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 3;
         bad = max(bad, a);
-        u32 bytes, nb;
-        rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a), md, bytes, nb);
+        u32 bytes, nb, z0 = 0, zn = 0;
+        rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a), md, bytes, nb, z0, zn, o, lds);
         o.put_bytes(lds, bytes, nb);
-        while (nb == 4 && rg_needs_byte(low, range)) {
-            o.put_bytes(lds, low >> 24, 1);
-            low <<= 8;
-            range <<= 8;
-        }
         if ((i & 15u) == 15u) o.maybe_flush(lds);
     }
     o.maybe_flush(lds);
@@ -467,35 +462,40 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         range = rr * e.y;
     }
     const u32 lk = r.look();
-    u32 nb = 0;
-    // closed form of the common case, see rg_encode_symbol
-    const u32 nb1 = (u32)__builtin_clz(low ^ (low + range)) >> 3;
+    // closed form of the common case computed unconditionally, ONE branch for everything rare (see rg_encode_symbol)
+    const u32 low0 = low, range0 = range, state0 = state;
+    const u32 nb1 = (u32)__builtin_clz(low0 ^ (low0 + range0)) >> 3;
     const u32 sh = 8 * nb1;
-    const u32 range_s = range << sh;
-    if (__builtin_expect(range_s >= RG_BOTTOM, 1)) {
-        state = (u32)(((((u64)state) << 32) | lk) << sh >> 32);  // the next nb1 bytes (sh may be 0): one 64-bit shift
-        low <<= sh;
-        range = range_s;
-        r.advance(lds, sh);
-        return s;
-    }
+    const u32 range_s = range0 << sh;
+    state = (u32)(((((u64)state0) << 32) | lk) << sh >> 32);  // the next nb1 bytes (sh may be 0): one 64-bit shift
+    low = low0 << sh;
+    range = range_s;
+    u32 adv = sh;
+    if (__builtin_expect(range_s < RG_BOTTOM, 0)) {
+        low = low0;
+        range = range0;
+        state = state0;
+        u32 nb = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool settled = ((low ^ (low + range)) < RG_TOP);
-        if (!settled && range >= RG_BOTTOM) break;
-        if (!settled) range = (0u - low) & (RG_BOTTOM - 1);
-        state = (state << 8) | ((lk >> (24 - 8 * j)) & 0xFFu);
-        ++nb;
-        low <<= 8;
-        range <<= 8;
+        for (int j = 0; j < 4; ++j) {
+            const bool settled = ((low ^ (low + range)) < RG_TOP);
+            if (!settled && range >= RG_BOTTOM) break;
+            if (!settled) range = (0u - low) & (RG_BOTTOM - 1);
+            state = (state << 8) | ((lk >> (24 - 8 * j)) & 0xFFu);
+            ++nb;
+            low <<= 8;
+            range <<= 8;
+        }
+        r.advance(lds, 8 * nb);
+        adv = 0;
+        while (nb == 4 && rg_needs_byte(low, range)) {  // mirror of the encoder's guard
+            state = (state << 8) | (r.look() >> 24);
+            r.advance(lds, 8);
+            low <<= 8;
+            range <<= 8;
+        }
     }
-    r.advance(lds, 8 * nb);
-    while (nb == 4 && rg_needs_byte(low, range)) {  // mirror of the encoder's guard
-        state = (state << 8) | (r.look() >> 24);
-        r.advance(lds, 8);
-        low <<= 8;
-        range <<= 8;
-    }
+    r.advance(lds, adv);
     return s;
 }
 
