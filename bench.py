@@ -48,7 +48,33 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
     ap.add_argument("--sym-pad", type=int, default=0, help="experiment: extra bytes between input rows")
+    ap.add_argument("--source", choices=["iid", "markov1"], default="iid",
+                    help="static-model coders: i.i.d. symbols with p = f/M of --table (the headline), or an order-1 Markov "
+                         "byte source (north_star's second source) coded with the table its own histogram gives "
+                         "(scl_histogram_u8 + normalize_counts, M = 4096)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` launched like the N = 1 headline (no RANK in the environment): start the N ranks
+    ourselves, one process per GPU, by re-executing this file under torch.distributed.run; rank 0 of the children prints
+    the one JSON line, which passes through.  Returns the children's exit code."""
+    import socket
+    import subprocess
+
+    import torch
+
+    shared = os.environ.get("SCL_BENCH_SHARED_GPU") == "1"
+    have = torch.cuda.device_count()
+    if not shared and have < args.gpus:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this node\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def make_model(args, freq):
@@ -214,6 +240,8 @@ def load_traffic_note():
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -243,14 +271,31 @@ def main():
 
     freq = {"t256": bench_data.t256_table, "uniform": bench_data.uniform256_table,
             "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
-    model, coder_params = make_model(args, freq)
     n_chunks, chunk_len = args.chunks, args.chunk_len
-    if args.coder == "aec" and args.aec_model == "order1":
-        # configs[3]: Markov-1 source (S4 of SURVEY 8d); 256 distinct chunks generated on the host, tiled to the batch
-        base = np.stack([bench_data.markov1_host(args.aec_K, chunk_len, seed=4 + 1000 * rank + i) for i in range(256)])
-        sym = torch.from_numpy(base).to(dev).repeat((n_chunks + 255) // 256, 1)[:n_chunks].contiguous()
+    static_model = args.coder != "aec" or args.aec_model == "fixed"
+    source_note = f"256-symbol static table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M"
+    if not static_model:
+        # configs[3]: Markov-1 source (S4 of SURVEY 8d), every chunk its own chain, generated on the device: the whole
+        # batch is distinct data (a tiled batch would be served from L2 and is not an HBM measurement)
+        sym = bench_data.markov1_chunks_device(args.aec_K, n_chunks, chunk_len, seed=4000 + rank, device=dev)
+        source_note = f"order-1 adaptive model, K={args.aec_K}, Markov-1 source (all chunks distinct)"
+    elif args.source == "markov1":
+        # north_star's second source for the static coders: Markov-1 bytes; the table is what the data's own histogram
+        # gives (row f3: scl_histogram_u8 + the deterministic normaliser), every symbol present so that f >= 1
+        from stanford_compression_library_amd.backend.modeling import histogram_u8, normalize_counts
+
+        sym = bench_data.markov1_chunks_device(256, n_chunks, chunk_len, seed=4000 + rank, device=dev)
+        counts = histogram_u8(sym) + 1
+        if world > 1:  # every rank codes with the same table: the histogram of all shards
+            t = torch.from_numpy(counts).to("cpu" if shared_gpu else dev)
+            dist.all_reduce(t)
+            counts = t.cpu().numpy()
+        freq = normalize_counts(counts, 65536 if args.coder == "range" and args.table == "uniform1" else 4096)
+        source_note = (f"order-1 Markov byte source (Dirichlet(0.3) rows, all chunks distinct), static table = normalised "
+                       f"histogram of the data (M={int(freq.sum())})")
     else:
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
+    model, coder_params = make_model(args, freq)
     if args.sym_pad:
         padded = torch.zeros((n_chunks, chunk_len + args.sym_pad), dtype=torch.uint8, device=dev)
         padded[:, :chunk_len] = sym
@@ -408,9 +453,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"batched {args.coder}: {n_chunks} independent "
                                    f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
-                                   + (f"256-symbol static table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M"
-                                      if (args.coder != "aec" or args.aec_model == "fixed")
-                                      else f"order-1 adaptive model, K={args.aec_K}, Markov-1 source"),
+                                   + source_note, "source": args.source if static_model else "markov1",
                        "coder": args.coder, **coder_params, "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
                        "bits_per_symbol_out": round(bits_per_symbol, 4), "sharding": f"{world} x independent shards"},
             "encode_MBps": round(total_bytes / (enc_ms * 1e-3) / 1e6, 2),

@@ -91,6 +91,8 @@ typedef struct scl_rans_info {
     uint32_t fast_path;      /* 1 if tuned kernels serve this model: u32 state with NUM_BITS_OUT = 1
                                 and any total <= 4096, or NUM_BITS_OUT in {2,4,8,16} with a
                                 power-of-two total <= 4096 (RANGE_FACTOR a power of two)        */
+    int32_t device;          /* the HIP device the handle's tables live on (current at create);
+                                batch calls refuse any other current device                     */
 } scl_rans_info;
 
 /* rANSParams(freqs, DATA_BLOCK_SIZE_BITS, NUM_BITS_OUT, RANGE_FACTOR) -> device-resident tables.
@@ -207,6 +209,9 @@ int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in, uint64_t i
  * block i+1 with the counts and the order-k context block i left behind.  The *_resume entry points
  * reproduce that: chunk c of the call CONTINUES coder c of a caller-owned device state buffer
  * (scl_aec_state_bytes(m, n_coders) bytes, 256-byte aligned) and leaves the advanced state there.
+ * The layout of the state buffer is a function of the n_coders it was reset with, so every call names that SAME
+ * n_coders (state_bytes >= scl_aec_state_bytes(m, n_coders)); a batch may continue fewer coders than the state
+ * holds (n_chunks <= n_coders: chunk c continues coder c), never more.
  * They run the any-parameter kernels.  FIXED models have nothing to carry and forward to the
  * plain entry points (d_state may be NULL).
  *
@@ -229,12 +234,13 @@ int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t *d_sym, ui
                                 const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
                                 uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
                                 uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
-                                uint64_t state_bytes, void *stream);
+                                uint64_t state_bytes, uint64_t n_coders, void *stream);
 int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
                                 const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
                                 uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
                                 uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
-                                uint32_t *d_status, void *d_state, uint64_t state_bytes, void *stream);
+                                uint32_t *d_status, void *d_state, uint64_t state_bytes, uint64_t n_coders,
+                                void *stream);
 
 /* ---- stream compaction / framing ------------------------------------------------------------ */
 #define SCL_COMPACT_DENSE 0  /* stream c left-aligned at byte d_out_byte_offset[c], zero tail   */
@@ -261,17 +267,29 @@ int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const
  *   scl_rccl_comm_create    : collective over the `world` ranks; the communicator belongs to the current device;
  *   scl_rccl_allgather_u64  : collective; one u64 per rank -> h_out[world] on every rank (synchronises `stream`):
  *                             the byte counts, so that the root can size its buffer before anything is posted;
+ *   scl_rccl_allgather_async: collective, asynchronous on `stream`, device to device: n_u64 values per rank ->
+ *                             d_out[world * n_u64] on every rank; nothing waits for the host (the overlapped
+ *                             pipeline queues it behind a sub-batch's compaction and reads it back with an event);
  *   scl_streams_gather_rccl : collective, asynchronous on `stream`: rank r's send_bytes bytes arrive at the root's
  *                             d_recv + h_rank_offsets[r]; h_rank_offsets[world + 1] (host) = exclusive prefix sum
- *                             of the counts, last entry = total.  d_recv matters on the root only.  Call it again
- *                             to move the per-chunk offset tables. */
+ *                             of the counts, last entry = total.  d_recv matters on the root only;
+ *   scl_streams_gatherv_rccl: n_parts such gathers (a payload and its per-chunk offset table, say) in ONE grouped
+ *                             exchange: part p moves h_send_bytes[p] bytes from d_send[p] to the root's d_recv[p]
+ *                             + h_rank_offsets[p * (world + 1) + r].
+ *   Errors: all arguments are checked before anything is posted; after ncclGroupStart the group is closed on every
+ *   path (first error recorded, ncclGroupEnd, then return).  A layout that contradicts this rank's own count is
+ *   refused on this rank only -- the peers then wait in the exchange, so derive layouts from exchanged counts. */
 typedef struct scl_comm scl_comm;
 int scl_rccl_unique_id(uint8_t *id128);
 int scl_rccl_comm_create(const uint8_t *id128, int rank, int world, scl_comm **out);
 void scl_rccl_comm_destroy(scl_comm *c);
 int scl_rccl_allgather_u64(scl_comm *c, uint64_t value, uint64_t *h_out, void *stream);
+int scl_rccl_allgather_async(scl_comm *c, const uint64_t *d_in, uint64_t *d_out, uint64_t n_u64, void *stream);
 int scl_streams_gather_rccl(scl_comm *c, int root, const uint8_t *d_send, uint64_t send_bytes, uint8_t *d_recv,
                             const uint64_t *h_rank_offsets, void *stream);
+int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts, const uint8_t *const *d_send,
+                             const uint64_t *h_send_bytes, uint8_t *const *d_recv, const uint64_t *h_rank_offsets,
+                             void *stream);
 
 /* ---- model construction helper (row f3): symbol histogram ------------------------------------------ */
 /* d_counts[256] (uint64) += number of occurrences of every byte value in d_sym[0..n).  The caller zeroes

@@ -33,7 +33,7 @@ class SclHipError(RuntimeError):
 class RansInfo(C.Structure):
     _fields_ = [("M", C.c_uint64), ("L", C.c_uint64), ("H", C.c_uint64), ("K", C.c_uint32),
                 ("num_state_bits", C.c_uint32), ("size_bits", C.c_uint32), ("num_bits_out", C.c_uint32),
-                ("max_bits_per_symbol", C.c_uint32), ("fast_path", C.c_uint32)]
+                ("max_bits_per_symbol", C.c_uint32), ("fast_path", C.c_uint32), ("device", C.c_int32)]
 
 
 _u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
@@ -87,8 +87,8 @@ _SIGNATURES = {
     "scl_aec_state_reset": (_int, [_vp, _vp, _u64, _u64, _vp]),
     "scl_aec_state_upload": (_int, [_vp, _vp, _u64, _u64, _u32p, _u32p, _vp]),
     "scl_aec_state_download": (_int, [_vp, _vp, _u64, _u64, _u32p, _u32p, _vp]),
-    "scl_aec_encode_batch_resume": (_int, _ENC_BATCH[:-1] + [_vp, _u64, _vp]),
-    "scl_aec_decode_batch_resume": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _vp]),
+    "scl_aec_encode_batch_resume": (_int, _ENC_BATCH[:-1] + [_vp, _u64, _u64, _vp]),
+    "scl_aec_decode_batch_resume": (_int, _DEC_BATCH[:-1] + [_vp, _u64, _u64, _vp]),
     "scl_aec_encode_host_resume": (_int, _ENC_HOST + [_u32p, _u32p]),
     "scl_aec_decode_host_resume": (_int, _DEC_HOST + [_u32p, _u32p]),
     "scl_streams_compact_scratch_bytes": (_u64, [_u64]),
@@ -99,7 +99,9 @@ _SIGNATURES = {
     "scl_rccl_comm_create": (_int, [_u8p, _int, _int, C.POINTER(_vp)]),
     "scl_rccl_comm_destroy": (None, [_vp]),
     "scl_rccl_allgather_u64": (_int, [_vp, _u64, _u64p, _vp]),
+    "scl_rccl_allgather_async": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "scl_streams_gather_rccl": (_int, [_vp, _int, _vp, _u64, _vp, _u64p, _vp]),
+    "scl_streams_gatherv_rccl": (_int, [_vp, _int, _u32, C.POINTER(_vp), _u64p, C.POINTER(_vp), _u64p, _vp]),
 }
 
 _lib = None

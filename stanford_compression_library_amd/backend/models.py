@@ -307,7 +307,9 @@ class AecModel(_DeviceModel):
         return out[: n_out.value], int(used.value)
 
     def alloc_state(self, n_coders: int, device):
-        """device state of n fresh coder objects (for encode_batch_resume / decode_batch_resume)"""
+        """device state of n fresh coder objects (for encode_batch_resume / decode_batch_resume).  The buffer's
+        layout depends on ``n_coders``; it is remembered on the tensor (``state.n_coders``) and handed to every
+        resume call, which refuses batches longer than that."""
         import torch
 
         nbytes = int(self._L.scl_aec_state_bytes(self._h, int(n_coders)))
@@ -316,15 +318,28 @@ class AecModel(_DeviceModel):
             rc = self._L.scl_aec_state_reset(self._h, state.data_ptr(), state.numel(), int(n_coders),
                                              torch.cuda.current_stream(device).cuda_stream)
         _lib.check(rc, "scl_aec_state_reset")
+        state.n_coders = int(n_coders)
         return state
+
+    @staticmethod
+    def _state_coders(state, n_chunks: int) -> int:
+        n_coders = getattr(state, "n_coders", None)
+        if n_coders is None:
+            raise AssertionError("state does not come from AecModel.alloc_state (its layout depends on n_coders)")
+        if n_chunks > n_coders:
+            raise AssertionError(f"{n_chunks} chunks but the state holds {n_coders} coders")
+        return int(n_coders)
 
     def state_download(self, state, n_coders: int, coder: int):
         import torch
 
+        assert int(n_coders) == self._state_coders(state, 0), "n_coders differs from the one the state was made with"
         counts = np.zeros(max(self.state_counts(), 1), np.uint32)
         past = np.zeros(4, np.uint32)
-        rc = self._L.scl_aec_state_download(self._h, state.data_ptr(), int(n_coders), int(coder), _lib.u32_ptr(counts),
-                                            _lib.u32_ptr(past), torch.cuda.current_stream(state.device).cuda_stream)
+        with torch.cuda.device(state.device):
+            rc = self._L.scl_aec_state_download(self._h, state.data_ptr(), int(n_coders), int(coder),
+                                                _lib.u32_ptr(counts), _lib.u32_ptr(past),
+                                                torch.cuda.current_stream(state.device).cuda_stream)
         _lib.check(rc, "scl_aec_state_download")
         return counts[: self.state_counts()], past
 
@@ -335,6 +350,7 @@ class AecModel(_DeviceModel):
 
         assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
+        n_coders = self._state_coders(state, n_chunks)
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, sym.device, out_stride)
         st = stream if stream is not None else torch.cuda.current_stream(sym.device).cuda_stream
@@ -342,7 +358,7 @@ class AecModel(_DeviceModel):
             rc = self._L.scl_aec_encode_batch_resume(
                 self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None, chunk_len,
                 n_chunks, out.data.data_ptr(), out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
-                out.status.data_ptr(), state.data_ptr(), state.numel(), st)
+                out.status.data_ptr(), state.data_ptr(), state.numel(), n_coders, st)
         _lib.check(rc, "scl_aec_encode_batch_resume")
         return out
 
@@ -350,6 +366,7 @@ class AecModel(_DeviceModel):
         import torch
 
         n_chunks = int(bit_offset.numel())
+        n_coders = self._state_coders(state, n_chunks)
         dev = data.device
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
@@ -357,7 +374,7 @@ class AecModel(_DeviceModel):
             rc = self._L.scl_aec_decode_batch_resume(
                 self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
                 sym.data_ptr(), sym.stride(0), int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr(),
-                state.data_ptr(), state.numel(), st)
+                state.data_ptr(), state.numel(), n_coders, st)
         _lib.check(rc, "scl_aec_decode_batch_resume")
         return sym[:, :chunk_cap], lens, used, status
 

@@ -75,17 +75,48 @@ class RcclGather:
         except Exception:
             pass
 
-    def sizes(self, nbytes: int, stream=None) -> np.ndarray:
-        """all ranks' byte counts as exclusive prefix offsets [world + 1] (collective; synchronises the stream)"""
+    def counts(self, value: int, stream=None) -> np.ndarray:
+        """one u64 of every rank, in rank order (collective; synchronises the stream)"""
         import torch
 
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         counts = np.zeros(self.world, dtype=np.uint64)
         with torch.cuda.device(self.device):
-            rc = self._L.scl_rccl_allgather_u64(self._h, int(nbytes), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+            rc = self._L.scl_rccl_allgather_u64(self._h, int(value), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                 st.cuda_stream)
         self._check(rc, "scl_rccl_allgather_u64")
-        return np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        return counts
+
+    def sizes(self, nbytes: int, stream=None) -> np.ndarray:
+        """all ranks' byte counts as exclusive prefix offsets [world + 1] (collective; synchronises the stream)"""
+        return np.concatenate([[0], np.cumsum(self.counts(nbytes, stream))]).astype(np.uint64)
+
+    def allgather_async(self, d_in, d_out, stream=None):
+        """asynchronous on ``stream``, device to device: every rank's int64 tensor ``d_in`` [n] -> ``d_out`` [world, n]"""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        assert d_in.dtype == torch.int64 and d_out.dtype == torch.int64 and d_out.numel() == self.world * d_in.numel()
+        with torch.cuda.device(self.device):
+            rc = self._L.scl_rccl_allgather_async(self._h, d_in.data_ptr(), d_out.data_ptr(), d_in.numel(), st.cuda_stream)
+        self._check(rc, "scl_rccl_allgather_async")
+
+    def gatherv(self, parts, root: int = 0, stream=None):
+        """several variable-length gathers in ONE grouped exchange, asynchronous on ``stream``.  ``parts``: list of
+        (payload uint8 tensor or None, nbytes, offsets uint64 [world + 1], out uint8 tensor or None)."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        n = len(parts)
+        send = (C.c_void_p * n)(*[p[0].data_ptr() if (p[0] is not None and p[1]) else None for p in parts])
+        recv = (C.c_void_p * n)(*[p[3].data_ptr() if p[3] is not None else None for p in parts])
+        nbytes = (C.c_uint64 * n)(*[int(p[1]) for p in parts])
+        offs = np.ascontiguousarray(np.stack([np.asarray(p[2], dtype=np.uint64) for p in parts]))
+        assert offs.shape == (n, self.world + 1)
+        with torch.cuda.device(self.device):
+            rc = self._L.scl_streams_gatherv_rccl(self._h, int(root), n, send, nbytes, recv,
+                                                  offs.ctypes.data_as(C.POINTER(C.c_uint64)), st.cuda_stream)
+        self._check(rc, "scl_streams_gatherv_rccl")
 
     def gather(self, payload, nbytes: int, offsets: np.ndarray, out=None, root: int = 0, stream=None):
         """asynchronous on ``stream``: this rank's ``payload[:nbytes]`` (uint8, device) -> ``out[offsets[rank]:]`` on the root"""
@@ -141,9 +172,12 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
     n_local = int(offsets.numel()) - 1
     my_bytes = int(offsets[-1].item())
     if comm is not None:
-        base = comm.sizes(my_bytes).astype(np.int64)
-        cbase = comm.sizes(8 * n_local).astype(np.int64) // 8
-        sizes, counts = np.diff(base), np.diff(cbase)
+        # one collective for both numbers: payload bytes in the low 40 bits, chunk count above
+        assert my_bytes < (1 << 40) and n_local < (1 << 24)
+        packed = comm.counts(my_bytes | (n_local << 40))
+        sizes, counts = (packed & np.uint64((1 << 40) - 1)).astype(np.int64), (packed >> np.uint64(40)).astype(np.int64)
+        base = np.concatenate([[0], np.cumsum(sizes)])
+        cbase = np.concatenate([[0], np.cumsum(counts)])
     else:
         meta = torch.tensor([my_bytes, n_local], dtype=torch.int64, device=device)
         all_meta = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
@@ -159,9 +193,9 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
         if rank == dst:
             out = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
             goffs = torch.empty(int(cbase[-1]) + 1, dtype=torch.int64, device=device)
-        comm.gather(dense, my_bytes, base.astype(np.uint64), out, root=dst)
-        comm.gather(local_offs.view(torch.uint8), 8 * n_local, (8 * cbase).astype(np.uint64),
-                    goffs.view(torch.uint8) if goffs is not None else None, root=dst)
+        comm.gatherv([(dense, my_bytes, base.astype(np.uint64), out),
+                      (local_offs.view(torch.uint8), 8 * n_local, (8 * cbase).astype(np.uint64),
+                       goffs.view(torch.uint8) if goffs is not None else None)], root=dst)
         torch.cuda.current_stream(device).synchronize()
         if out is not None:
             out = out[:total]
@@ -184,9 +218,17 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
 def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: int = 8, dst: int = 0,
                              comm: Optional[RcclGather] = None, framed: bool = False):
     """configs[4] end to end for this rank's shard ``sym`` (uint8 [n_chunks, chunk_len] on the device): the shard is
-    cut into ``n_sub`` sub-batches; each is encoded and compacted on the compute stream (nothing there waits for the
-    host), and its dense payload + per-chunk offsets are gathered to ``dst`` on a second stream while the NEXT
-    sub-batch is already running: the host enqueues sub-batch i + 1 before it waits for sub-batch i's byte count.
+    cut into ``n_sub`` sub-batches; ALL of them are queued on the compute stream up front (encode + compaction into
+    caller-owned worst-case buffers: nothing there ever waits for the host), and sub-batch i travels to ``dst`` on the
+    communication stream while the later ones are still being coded.
+
+    Host traffic per sub-batch with an :class:`RcclGather`: ONE asynchronous device-to-device all-gather carrying
+    ``{payload bytes, chunks}`` of every rank, ONE wait on the event behind its read-back (the root must know the
+    counts to post its receives), ONE grouped send / receive that moves the payload and the per-chunk offset table
+    together.  No ``.item()``, no stream synchronisation inside the loop.  The all-gather of sub-batch i + 1 is queued
+    BEFORE the exchange of sub-batch i, so its counts are already on the host when the exchange of i ends and the
+    communication stream never idles on a host round trip.  Without an RcclGather (gloo in the CPU tests, or a single
+    process) the per-sub-batch exchange goes through :func:`gather_streams_to_root`.
 
     Returns (timings dict, on the root a list of per-sub-batch (bytes, global_offsets) pairs in sub-batch order -- the
     root's buffer for sub-batch i holds the ranks' sub-batch-i payloads in rank order --, None elsewhere).
@@ -202,38 +244,83 @@ def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: int = 8, 
     bounds = [n_chunks * i // n_sub for i in range(n_sub + 1)]
     comp, comm_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     comp.wait_stream(torch.cuda.current_stream(dev))
+    comm_stream.wait_stream(torch.cuda.current_stream(dev))
     stride = model.slot_bytes(chunk_len)
-    jobs, results = [], []
+    # {payload bytes, chunks} per sub-batch: column 1 is known now, column 0 is written by the compute stream
+    h_counts = torch.tensor([[0, bounds[i + 1] - bounds[i]] for i in range(n_sub)], dtype=torch.int64)
+    meta = h_counts.to(dev)
+    all_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, device=dev)
+    h_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, pin_memory=True)
     t0 = time.perf_counter()
 
-    def enqueue(i):
-        a, b = bounds[i], bounds[i + 1]
-        with torch.cuda.stream(comp):
+    # ---- compute stream: everything, now ----------------------------------------------------------------------
+    jobs = []
+    with torch.cuda.stream(comp):
+        for i in range(n_sub):
+            a, b = bounds[i], bounds[i + 1]
             enc = model.encode_batch(sym[a:b], stream=comp.cuda_stream, out_stride=stride)
             dense = torch.empty(compact_capacity(b - a, stride, framed), dtype=torch.uint8, device=dev)
             offs = torch.empty(b - a + 1, dtype=torch.int64, device=dev)
             scratch = torch.empty(compact_scratch_bytes(b - a), dtype=torch.uint8, device=dev)
             compact_into(enc, dense, offs, scratch, framed=framed, stream=comp)
-            total = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            total.copy_(offs[-1:], non_blocking=True)
+            meta[i, 0:1].copy_(offs[b - a:], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(comp)
-        return dict(enc=enc, dense=dense, offs=offs, scratch=scratch, total=total, ev=ev)
+            for t in (dense, offs, meta):
+                t.record_stream(comm_stream)
+            jobs.append(dict(enc=enc, dense=dense, offs=offs, scratch=scratch, ev=ev, n=b - a))
 
-    def send(job):
-        job["ev"].synchronize()  # this sub-batch only: later ones keep running
-        comm_stream.wait_event(job["ev"])
-        with torch.cuda.stream(comm_stream):
-            if world > 1 or comm is not None:
-                return gather_streams_to_root(job["dense"], job["offs"], world, rank, dev, dst, return_data=True, comm=comm)
-            n = int(job["total"][0])
-            return n, job["dense"][:n], job["offs"]
+    results = []
+    if comm is not None:
+        # ---- RCCL: all-gather(i + 1) is queued ahead of exchange(i) ------------------------------------------
+        sizes_ready = []
 
-    for i in range(n_sub + 1):
-        if i < n_sub:
-            jobs.append(enqueue(i))
-        if i >= 1:
-            results.append(send(jobs[i - 1]))
+        def queue_sizes(i):
+            comm_stream.wait_event(jobs[i]["ev"])
+            with torch.cuda.stream(comm_stream):
+                comm.allgather_async(meta[i], all_meta[i], stream=comm_stream)
+                h_meta[i].copy_(all_meta[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+            sizes_ready.append(ev)
+
+        queue_sizes(0)
+        for i in range(n_sub):
+            if i + 1 < n_sub:
+                queue_sizes(i + 1)
+            sizes_ready[i].synchronize()  # the one host wait of this sub-batch: the counts of every rank
+            counts = h_meta[i].numpy()
+            base = np.concatenate([[0], np.cumsum(counts[:, 0])]).astype(np.uint64)
+            cbase = np.concatenate([[0], np.cumsum(counts[:, 1])]).astype(np.uint64)
+            job = jobs[i]
+            out = goffs = None
+            with torch.cuda.stream(comm_stream):
+                if rank == dst:
+                    out = torch.empty(max(int(base[-1]), 1), dtype=torch.uint8, device=dev)
+                    goffs = torch.empty(int(cbase[-1]) + 1, dtype=torch.int64, device=dev)
+                comm.gatherv([(job["dense"], int(counts[rank, 0]), base, out),
+                              (job["offs"].view(torch.uint8), 8 * job["n"], 8 * cbase,
+                               goffs.view(torch.uint8) if goffs is not None else None)], root=dst, stream=comm_stream)
+                if rank == dst:
+                    # offsets arrive relative to their own rank's buffer: one add of the per-chunk rank base
+                    if world > 1:
+                        shift = torch.from_numpy(np.repeat(base[:-1].astype(np.int64), counts[:, 1])).to(dev, non_blocking=True)
+                        goffs[:-1] += shift
+                    goffs[-1] = int(base[-1])
+                    out = out[:int(base[-1])]
+            results.append((int(base[-1]), out, goffs))
+    else:
+        # ---- any torch.distributed backend (gloo in the tests) / a single process ---------------------------
+        for i in range(n_sub):
+            job = jobs[i]
+            job["ev"].synchronize()
+            comm_stream.wait_event(job["ev"])
+            with torch.cuda.stream(comm_stream):
+                if world > 1:
+                    results.append(gather_streams_to_root(job["dense"], job["offs"], world, rank, dev, dst, return_data=True))
+                else:
+                    n = int(job["offs"][-1].item())
+                    results.append((n, job["dense"][:n], job["offs"]))
     comm_stream.synchronize()
     comp.synchronize()
     total_ms = (time.perf_counter() - t0) * 1e3

@@ -63,3 +63,32 @@ def markov1_host(K: int, n: int, seed: int = 4) -> np.ndarray:
         prev = min(int(np.searchsorted(cdf[prev], u[t], side="right")), K - 1)
         x[t] = prev
     return x
+
+
+def markov1_matrix(K: int, seed: int = 4) -> np.ndarray:
+    """S4 transition matrix: K rows ~ Dirichlet(0.3) (``default_rng(4)``)."""
+    return np.random.default_rng(seed).dirichlet(0.3 * np.ones(K), size=K)
+
+
+def markov1_chunks_device(K: int, n_chunks: int, chunk_len: int, seed: int, device, matrix_seed: int = 4):
+    """uint8 CUDA tensor [n_chunks, chunk_len]: every row is its own order-1 Markov chain over K symbols (one shared
+    transition matrix, ``x_-1 = 0``), generated on the device so that a 1 GiB batch is 1 GiB of DISTINCT
+    data.  The cumulative rows are quantised to 24 bits: a symbol is the number of thresholds its uniform draw passes."""
+    import torch
+
+    P = markov1_matrix(K, matrix_seed)
+    thresh = np.minimum(np.floor(np.cumsum(P, axis=1) * (1 << 24)), (1 << 24)).astype(np.int32)
+    thresh[:, -1] = 1 << 24  # the last symbol takes whatever mass rounding left
+    cdf = torch.from_numpy(thresh).to(device)  # [K, K]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    out = torch.empty((n_chunks, chunk_len), dtype=torch.uint8, device=device)
+    rows = max(1, min(n_chunks, (1 << 26) // max(K, 1)))  # bound the [rows, K] temporaries to 256 MiB
+    for a in range(0, n_chunks, rows):
+        b = min(n_chunks, a + rows)
+        prev = torch.zeros(b - a, dtype=torch.int64, device=device)
+        for t in range(chunk_len):
+            u = torch.randint(0, 1 << 24, (b - a, 1), dtype=torch.int32, device=device, generator=gen)
+            prev = (u >= cdf[prev]).sum(dim=1).clamp_(max=K - 1)
+            out[a:b, t] = prev.to(torch.uint8)
+    return out

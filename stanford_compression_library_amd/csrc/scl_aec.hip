@@ -778,7 +778,7 @@ extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t
                                            const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
                                            uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
                                            uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
-                                           uint64_t state_bytes, void *stream) {
+                                           uint64_t state_bytes, uint64_t n_coders, void *stream) {
     SCL_REQUIRE(m, "aec_encode_batch_resume: null model");
     if (int rc_dev = scl_check_device(m->device, "aec_encode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)  // nothing to carry
@@ -790,10 +790,14 @@ extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t
                 "aec_encode_batch_resume: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_state & 255) == 0,
                 "aec_encode_batch_resume: d_out must be 16-byte, d_state 256-byte aligned");
-    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_chunks), "aec_encode_batch_resume: state of %llu bytes required",
-                (unsigned long long)scl_aec_state_bytes(m, n_chunks));
+    // the layout of d_state is a function of the n_coders it was reset with (the context array follows the cells of
+    // ALL coders): chunk c continues coder c, so a batch may be shorter than the state, never longer
+    SCL_REQUIRE(n_chunks <= n_coders, "aec_encode_batch_resume: %llu chunks but the state holds %llu coders",
+                (unsigned long long)n_chunks, (unsigned long long)n_coders);
+    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_coders), "aec_encode_batch_resume: state of %llu bytes required",
+                (unsigned long long)scl_aec_state_bytes(m, n_coders));
     if (n_chunks == 0) return SCL_OK;
-    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_chunks));
+    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
     hipLaunchKernelGGL(aec_encode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        m->dev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                        d_out_nbits, d_status, (u32 *)d_state, ctx_state);
@@ -805,7 +809,7 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
                                            const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
                                            uint8_t *d_out_sym, uint64_t out_stride, uint32_t out_cap,
                                            uint32_t *d_out_lens, uint32_t *d_consumed, uint32_t *d_status,
-                                           void *d_state, uint64_t state_bytes, void *stream) {
+                                           void *d_state, uint64_t state_bytes, uint64_t n_coders, void *stream) {
     SCL_REQUIRE(m, "aec_decode_batch_resume: null model");
     if (int rc_dev = scl_check_device(m->device, "aec_decode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)
@@ -815,10 +819,14 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
                 "aec_decode_batch_resume: null pointer argument");
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0 && ((uintptr_t)d_state & 255) == 0,
                 "aec_decode_batch_resume: d_in must be 4-byte, d_state 256-byte aligned");
-    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_chunks), "aec_decode_batch_resume: state of %llu bytes required",
-                (unsigned long long)scl_aec_state_bytes(m, n_chunks));
+    // the layout of d_state is a function of the n_coders it was reset with (the context array follows the cells of
+    // ALL coders): chunk c continues coder c, so a batch may be shorter than the state, never longer
+    SCL_REQUIRE(n_chunks <= n_coders, "aec_decode_batch_resume: %llu chunks but the state holds %llu coders",
+                (unsigned long long)n_chunks, (unsigned long long)n_coders);
+    SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_coders), "aec_decode_batch_resume: state of %llu bytes required",
+                (unsigned long long)scl_aec_state_bytes(m, n_coders));
     if (n_chunks == 0) return SCL_OK;
-    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_chunks));
+    u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
     hipLaunchKernelGGL(aec_decode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        m->dev, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                        d_out_lens, d_consumed, d_status, (u32 *)d_state, ctx_state);
@@ -871,14 +879,14 @@ static int aec_state_post(const void *model, const void *d_scratch, void *user) 
 static int aec_run_enc_resume(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
                               u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes) {
     return scl_aec_encode_batch_resume((const scl_aec_model *)model, d_sym, n, nullptr, n, 1, d_out, out_stride,
-                                       d_bit_off, d_nbits, d_status, d_scratch, scratch_bytes, nullptr);
+                                       d_bit_off, d_nbits, d_status, d_scratch, scratch_bytes, 1, nullptr);
 }
 static int aec_run_dec_resume(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed,
                               u32 *d_status, void *d_scratch, u64 scratch_bytes) {
     return scl_aec_decode_batch_resume((const scl_aec_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
                                        d_out_sym, scl_round_up((u64)out_cap + 1, 16), out_cap, d_out_len, d_consumed,
-                                       d_status, d_scratch, scratch_bytes, nullptr);
+                                       d_status, d_scratch, scratch_bytes, 1, nullptr);
 }
 
 extern "C" int scl_aec_encode_host_resume(const scl_aec_model *m, const uint8_t *h_sym, uint64_t n, uint8_t *h_out,

@@ -15,7 +15,7 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 #define SCL_WAVE 64
-#define SCL_ABI_VERSION 2
+#define SCL_ABI_VERSION 3
 
 // ---- host-side error plumbing ------------------------------------------------------------------
 void scl_set_error(const char *fmt, ...);

@@ -54,10 +54,13 @@ static int rccl_load() {
         scl_set_error("rccl: librccl.so not found (%s)", dlerror());
         return SCL_E_NODEVICE;
     }
+    // resolved into a local table and published only when complete: a half-filled g_rccl is never visible
+    RcclApi api;
 #define SCL_RCCL_SYM(field, name)                                      \
-    *(void **)(&g_rccl.field) = dlsym(h, name);                        \
-    if (!g_rccl.field) {                                               \
+    *(void **)(&api.field) = dlsym(h, name);                           \
+    if (!api.field) {                                                  \
         scl_set_error("rccl: symbol %s missing from librccl.so", name); \
+        dlclose(h);                                                    \
         return SCL_E_NODEVICE;                                         \
     }
     SCL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
@@ -70,7 +73,8 @@ static int rccl_load() {
     SCL_RCCL_SYM(GroupEnd, "ncclGroupEnd")
     SCL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef SCL_RCCL_SYM
-    g_rccl.handle = h;
+    api.handle = h;
+    g_rccl = api;
     return SCL_OK;
 }
 
@@ -155,35 +159,81 @@ extern "C" int scl_rccl_allgather_u64(scl_comm *c, uint64_t value, uint64_t *h_o
     return SCL_OK;
 }
 
-// Collective, asynchronous on `stream`: rank r's send_bytes bytes at d_send arrive at the root's
-// d_recv + h_rank_offsets[r].  h_rank_offsets[world + 1] (host) is the layout every rank agreed on beforehand
-// (exclusive prefix sum of the counts from scl_rccl_allgather_u64, last entry = total): h_rank_offsets[r + 1] -
-// h_rank_offsets[r] must equal rank r's send_bytes.  d_recv matters on the root only.
-extern "C" int scl_streams_gather_rccl(scl_comm *c, int root, const uint8_t *d_send, uint64_t send_bytes, uint8_t *d_recv,
-                                       const uint64_t *h_rank_offsets, void *stream) {
-    SCL_REQUIRE(c && h_rank_offsets && root >= 0 && root < c->world && (d_send || send_bytes == 0),
-                "streams_gather_rccl: bad arguments");
-    if (int rc = scl_check_device(c->device, "streams_gather_rccl")) return rc;
+// Collective, asynchronous on `stream`, device to device: every rank contributes n_u64 values at d_in; d_out
+// [world * n_u64] receives all of them in rank order on every rank.  Nothing here waits for the host: the overlapped
+// pipeline of configs[4] queues it behind a sub-batch's compaction and reads the sizes back with an event.
+extern "C" int scl_rccl_allgather_async(scl_comm *c, const uint64_t *d_in, uint64_t *d_out, uint64_t n_u64, void *stream) {
+    SCL_REQUIRE(c && d_in && d_out && n_u64 >= 1, "rccl_allgather_async: bad arguments");
+    if (int rc = scl_check_device(c->device, "rccl_allgather_async")) return rc;
+    SCL_RCCL_TRY(g_rccl.AllGather(d_in, d_out, n_u64, scl_ncclUint64, c->comm, (hipStream_t)stream));
+    return SCL_OK;
+}
+
+// n_parts variable-length gathers in ONE grouped exchange, asynchronous on `stream`: for part p, rank r's
+// h_send_bytes[p] bytes at d_send[p] arrive at the root's d_recv[p] + h_rank_offsets[p * (world + 1) + r].
+// h_rank_offsets holds, per part, the layout every rank agreed on beforehand (exclusive prefix sum of the ranks'
+// counts, last entry = total); d_recv matters on the root only.  A payload and its per-chunk offset table travel as
+// two parts of one call.
+//
+// Failure behaviour: every argument is validated BEFORE anything is posted; a layout that disagrees with this rank's
+// own count is refused on this rank only -- its peers then wait in the exchange (a collective cannot be refused
+// unilaterally), so callers must derive the layout from exchanged counts (scl_rccl_allgather_*), never from guesses.
+// Once ncclGroupStart has succeeded, ncclGroupEnd is called on every path: the first error is recorded, the group
+// is closed, then the error is returned -- the thread never stays inside an open group.
+extern "C" int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts, const uint8_t *const *d_send,
+                                        const uint64_t *h_send_bytes, uint8_t *const *d_recv,
+                                        const uint64_t *h_rank_offsets, void *stream) {
+    SCL_REQUIRE(c && h_rank_offsets && d_send && h_send_bytes && root >= 0 && root < c->world && n_parts >= 1 &&
+                    n_parts <= 64,
+                "streams_gatherv_rccl: bad arguments");
+    if (int rc = scl_check_device(c->device, "streams_gatherv_rccl")) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int W = c->world;
-    SCL_REQUIRE(h_rank_offsets[c->rank + 1] - h_rank_offsets[c->rank] == send_bytes,
-                "streams_gather_rccl: rank %d sends %llu bytes but the agreed layout gives it %llu", c->rank,
-                (unsigned long long)send_bytes,
-                (unsigned long long)(h_rank_offsets[c->rank + 1] - h_rank_offsets[c->rank]));
-    SCL_REQUIRE(c->rank != root || d_recv || h_rank_offsets[W] == 0, "streams_gather_rccl: the root needs a receive buffer");
-    // one grouped exchange: every non-root rank sends, the root posts one receive per sender
-    SCL_RCCL_TRY(g_rccl.GroupStart());
-    if (c->rank == root) {
-        for (int r = 0; r < W; ++r) {
-            const u64 nb = h_rank_offsets[r + 1] - h_rank_offsets[r];
-            if (r != root && nb)
-                SCL_RCCL_TRY(g_rccl.Recv(d_recv + h_rank_offsets[r], nb, scl_ncclUint8, r, c->comm, st));
-        }
-    } else if (send_bytes) {
-        SCL_RCCL_TRY(g_rccl.Send(d_send, send_bytes, scl_ncclUint8, root, c->comm, st));
+    for (u32 p = 0; p < n_parts; ++p) {
+        const u64 *offs = h_rank_offsets + (u64)p * (W + 1);
+        SCL_REQUIRE(d_send[p] || h_send_bytes[p] == 0, "streams_gatherv_rccl: part %u has bytes but no send buffer", p);
+        SCL_REQUIRE(offs[c->rank + 1] - offs[c->rank] == h_send_bytes[p],
+                    "streams_gatherv_rccl: part %u: rank %d sends %llu bytes but the agreed layout gives it %llu", p,
+                    c->rank, (unsigned long long)h_send_bytes[p], (unsigned long long)(offs[c->rank + 1] - offs[c->rank]));
+        SCL_REQUIRE(c->rank != root || offs[W] == 0 || (d_recv && d_recv[p]),
+                    "streams_gatherv_rccl: the root needs a receive buffer for part %u", p);
     }
-    SCL_RCCL_TRY(g_rccl.GroupEnd());
-    if (c->rank == root && send_bytes)  // the root's own share: a device copy on the same stream
-        SCL_HIP_TRY(hipMemcpyAsync(d_recv + h_rank_offsets[root], d_send, send_bytes, hipMemcpyDeviceToDevice, st));
+    // one grouped exchange: every non-root rank sends its parts, the root posts one receive per sender and part
+    SCL_RCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t first = 0;
+    const char *what = "";
+    for (u32 p = 0; p < n_parts && first == 0; ++p) {
+        const u64 *offs = h_rank_offsets + (u64)p * (W + 1);
+        if (c->rank == root) {
+            for (int r = 0; r < W && first == 0; ++r) {
+                const u64 nb = offs[r + 1] - offs[r];
+                if (r != root && nb) {
+                    first = g_rccl.Recv(d_recv[p] + offs[r], nb, scl_ncclUint8, r, c->comm, st);
+                    what = "ncclRecv";
+                }
+            }
+        } else if (h_send_bytes[p]) {
+            first = g_rccl.Send(d_send[p], h_send_bytes[p], scl_ncclUint8, root, c->comm, st);
+            what = "ncclSend";
+        }
+    }
+    const ncclResult_t end = g_rccl.GroupEnd();  // always: never leave the thread's group open
+    if (first != 0 || end != 0) {
+        scl_set_error("streams_gatherv_rccl: %s failed: %s", first != 0 ? what : "ncclGroupEnd",
+                      g_rccl.GetErrorString(first != 0 ? first : end));
+        return SCL_E_HIP;
+    }
+    if (c->rank == root)  // the root's own share: device copies on the same stream
+        for (u32 p = 0; p < n_parts; ++p)
+            if (h_send_bytes[p])
+                SCL_HIP_TRY(hipMemcpyAsync(d_recv[p] + h_rank_offsets[(u64)p * (W + 1) + root], d_send[p], h_send_bytes[p],
+                                           hipMemcpyDeviceToDevice, st));
     return SCL_OK;
+}
+
+// The one-part form (ABI version 2 signature): rank r's send_bytes bytes at d_send arrive at the root's
+// d_recv + h_rank_offsets[r].
+extern "C" int scl_streams_gather_rccl(scl_comm *c, int root, const uint8_t *d_send, uint64_t send_bytes, uint8_t *d_recv,
+                                       const uint64_t *h_rank_offsets, void *stream) {
+    return scl_streams_gatherv_rccl(c, root, 1, &d_send, &send_bytes, &d_recv, h_rank_offsets, stream);
 }

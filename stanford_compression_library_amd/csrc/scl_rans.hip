@@ -168,8 +168,8 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
     unsigned __int128 H = (L << b) - 1;
     SCL_REQUIRE((H >> 63) == 0, "rans_model_create: H >= 2^63 overflows the reference's int64 state (quirk Q7)");
     scl_rans_model *m = new scl_rans_model();
-    m->device = scl_current_device();
     ::memset((void *)m, 0, sizeof(*m));
+    m->device = scl_current_device();  // AFTER the memset: the batch entry points check it (scl_check_device)
     m->dev.K = K;
     m->dev.b = b;
     m->dev.size_bits = size_bits;
@@ -239,6 +239,7 @@ extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info)
     info->num_bits_out = m->dev.b;
     info->max_bits_per_symbol = m->max_bits_per_symbol;
     info->fast_path = m->fast | m->fastb;
+    info->device = m->device;
     return SCL_OK;
 }
 

@@ -309,6 +309,7 @@ extern "C" int scl_tans_model_info(const scl_tans_model *m, scl_rans_info *info)
     info->num_bits_out = 1;
     info->max_bits_per_symbol = m->max_bits_per_symbol;
     info->fast_path = (m->fast || m->rans) ? 1u : m->dev.lds_tables;
+    info->device = m->device;
     return SCL_OK;
 }
 

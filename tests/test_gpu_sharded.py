@@ -66,20 +66,28 @@ WORKER = textwrap.dedent("""
     from stanford_compression_library_amd import bench_data
     from stanford_compression_library_amd.backend import models
     from stanford_compression_library_amd.backend.sharded import shard_range, encode_gather_overlapped, gather_streams_to_root
+    from stanford_compression_library_amd.backend.sharded import RcclGather
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda:0")
+    rccl = {rccl!r}
+    dev = torch.device("cuda", rank if rccl else 0)
+    torch.cuda.set_device(dev)
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = RcclGather(world, rank, dev) if rccl else None   # a second communicator beside torch's
     freq = bench_data.t256_table()
-    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)   # on cuda:rank -- the handle must record THAT device
+    assert model.info().device == dev.index
     n_chunks, chunk_len = 1000, 384
     sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=31, device=dev)   # same on both ranks
     a, b = shard_range(n_chunks, world, rank)
     # (1) plain gather of the rank's whole shard
     enc = model.encode_batch(sym[a:b])
     dense, offs = models.compact(enc)
-    total, out, goffs = gather_streams_to_root(dense, offs, world, rank, dev, return_data=True)
+    total, out, goffs = gather_streams_to_root(dense, offs, world, rank, dev, return_data=True, comm=comm)
     # (2) the overlapped pipeline, 3 sub-batches per rank
-    timings, parts = encode_gather_overlapped(model, sym[a:b], world, rank, n_sub=3)
+    timings, parts = encode_gather_overlapped(model, sym[a:b], world, rank, n_sub=3, comm=comm)
     if rank == 0:
         ref_enc = model.encode_batch(sym)
         ref, ref_offs = models.compact(ref_enc)
@@ -101,17 +109,19 @@ WORKER = textwrap.dedent("""
             seen += len(idx)
         assert seen == n_chunks and timings["gathered_bytes"] == n
         print("SHARDED_GPU_OK", n, timings)
+    if comm is not None:
+        comm.close()
     dist.destroy_process_group()
 """)
 
 
-def test_two_ranks_share_the_gpu_gloo(tmp_path):
+def _run_two_ranks(tmp_path, rccl):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, rccl=rccl))
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -120,3 +130,75 @@ def test_two_ranks_share_the_gpu_gloo(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDED_GPU_OK" in outs[0]
+
+
+def test_two_ranks_share_the_gpu_gloo(tmp_path):
+    _run_two_ranks(tmp_path, rccl=False)
+
+
+def test_two_ranks_two_gpus_rccl(tmp_path):
+    """the real thing, whenever the box has two devices: two ranks on cuda:0 / cuda:1, torch's RCCL process group plus
+    the C ABI's own communicator; ncclAllGather / grouped ncclSend / ncclRecv meet a peer; the plain gather and the
+    overlapped pipeline are compared chunk by chunk with a one-process run.  Also covers model handles created on a
+    device other than 0."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (the gpurun pool hands out one-GPU boxes)")
+    _run_two_ranks(tmp_path, rccl=True)
+
+
+def test_model_records_its_device():
+    """the rANS handle used to record device 0 whatever was current at create"""
+    from stanford_compression_library_amd import bench_data
+    from stanford_compression_library_amd.backend import lib, models
+
+    lib.require_device()
+    last = torch.cuda.device_count() - 1
+    freq = bench_data.t256_table()
+    with torch.cuda.device(last):
+        model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+        tmodel = models.TansModel(freq.tolist(), 1, 32)
+        assert model.info().device == last and tmodel.info().device == last
+        dev = torch.device("cuda", last)
+        sym = bench_data.iid_chunks_device(freq, 64, 256, seed=3, device=dev)
+        enc = model.encode_batch(sym)
+        dec = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, 256)
+        assert torch.equal(dec[0], sym)
+    if last > 0:  # a foreign current device is refused, not dereferenced
+        with torch.cuda.device(0), pytest.raises(lib.SclHipError):
+            L = lib.load()
+            st = torch.cuda.current_stream(0).cuda_stream
+            sym0 = sym.to("cuda:0")
+            out = model.alloc_encoded(64, 256, torch.device("cuda:0"))
+            lib.check(L.scl_rans_encode_batch(model._h, sym0.data_ptr(), 256, None, 256, 64, out.data.data_ptr(),
+                                              out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
+                                              out.status.data_ptr(), st), "scl_rans_encode_batch")
+
+
+def test_rccl_gatherv_refuses_bad_layout_without_leaving_a_group_open():
+    """error paths of scl_streams_gatherv_rccl: arguments are validated before anything is posted, and a later
+    collective on the same communicator still works"""
+    from stanford_compression_library_amd.backend import lib
+    from stanford_compression_library_amd.backend.sharded import RcclGather
+
+    lib.require_device()
+    dev = torch.device("cuda:0")
+    comm = RcclGather(1, 0, dev)
+    try:
+        payload = torch.arange(100, dtype=torch.uint8, device=dev)
+        out = torch.zeros(100, dtype=torch.uint8, device=dev)
+        with pytest.raises(lib.SclHipError, match="agreed layout"):
+            comm.gatherv([(payload, 100, np.array([0, 99], np.uint64), out)])
+        with pytest.raises(lib.SclHipError, match="receive buffer"):
+            comm.gatherv([(payload, 100, np.array([0, 100], np.uint64), None)])
+        comm.gatherv([(payload, 100, np.array([0, 100], np.uint64), out),
+                      (payload[:7], 7, np.array([0, 7], np.uint64), out[50:])])
+        torch.cuda.synchronize()
+        assert torch.equal(out[:50], payload[:50]) and torch.equal(out[50:57], payload[:7])
+        assert list(comm.counts(12345)) == [12345]
+        a = torch.tensor([5, 6], dtype=torch.int64, device=dev)
+        b = torch.zeros((1, 2), dtype=torch.int64, device=dev)
+        comm.allgather_async(a, b)
+        torch.cuda.synchronize()
+        assert b.tolist() == [[5, 6]]
+    finally:
+        comm.close()

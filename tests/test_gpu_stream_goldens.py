@@ -179,16 +179,19 @@ def test_batch_resume_vs_oracle(model, K, k, freq, max_total, dev):
     o_enc = [orc.aec_fresh_state(kind, K, k, freq) for _ in range(n_coders)]
     o_dec = [s.copy() for s in o_enc]
     kw = dict(model_kind=kind, K=K, k=k, f_init=freq, max_total=max_total)
-    for blk in range(3):
-        sym = rng.integers(0, K, (n_coders, width)).astype(np.uint8)
-        lens = rng.integers(0 if blk else 1, width + 1, n_coders).astype(np.int32)
+    for blk in range(4):
+        # block 3 continues only the first 11 coders of the 37-coder state (the state's layout is that of
+        # the n_coders it was reset with, whatever the length of the batch that resumes it)
+        n_now = n_coders if blk < 3 else 11
+        sym = rng.integers(0, K, (n_now, width)).astype(np.uint8)
+        lens = rng.integers(0 if blk else 1, width + 1, n_now).astype(np.int32)
         lens[0] = width
         enc = m.encode_batch_resume(torch.from_numpy(sym).to(dev), st_enc, lens=torch.from_numpy(lens).to(dev))
         torch.cuda.synchronize()
         assert not enc.status.cpu().numpy().any()
         data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
         keep = lens > 0  # the reference's decoder never terminates on an empty block (quirk Q5)
-        for c in range(n_coders):
+        for c in range(n_now):
             ref, rn = orc.aec_encode(sym[c, :lens[c]], state=o_enc[c], **kw)
             assert rn == int(nbits[c]), (blk, c)
             got = np.unpackbits(data[offs[c] // 8: offs[c] // 8 + (rn + 7) // 8])[:rn]
@@ -197,7 +200,7 @@ def test_batch_resume_vs_oracle(model, K, k, freq, max_total, dev):
         torch.cuda.synchronize()
         assert not status.cpu().numpy().any()
         dsym, dlens, used = dsym.cpu().numpy(), dlens.cpu().numpy(), used.cpu().numpy()
-        for c in range(n_coders):
+        for c in range(n_now):
             assert dlens[c] == lens[c]
             assert np.array_equal(dsym[c, :lens[c]], sym[c, :lens[c]])
             if keep[c]:
@@ -208,7 +211,9 @@ def test_batch_resume_vs_oracle(model, K, k, freq, max_total, dev):
                                                 state=o_dec[c], **kw)
                 assert used[c] == ref_used and np.array_equal(back, sym[c, :lens[c]])
                 assert ref_used == nbits[c] or lens[c] <= 2
-    for c in (0, 1, n_coders - 1):
+    with pytest.raises(AssertionError):  # more chunks than the state has coders
+        m.encode_batch_resume(torch.zeros((n_coders + 1, 16), dtype=torch.uint8, device=dev), st_enc)
+    for c in (0, 1, 10, 11, n_coders - 1):
         for st, oracle_state in ((st_enc, o_enc[c]), (st_dec, o_dec[c])):
             counts, past = m.state_download(st, n_coders, c)
             assert np.array_equal(counts.astype(np.uint64), oracle_state[:-1])

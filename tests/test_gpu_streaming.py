@@ -124,6 +124,28 @@ def test_bench_two_ranks_on_one_gpu():
     assert all(g[k] > 0 for k in ("encode_ms", "compact_ms", "gather_ms", "sequential_ms", "overlapped_ms"))
 
 
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 --gather` launched like the headline (no torchrun, no RANK in the environment) starts its
+    two ranks itself and still prints exactly one JSON line (VERDICT r2 "missing" #1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SCL_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunks",
+           "4096", "--no-cpu-baseline", "--gather"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["round_trip_verified"] and out["gather"]["blocks_1MiB"] == 2 * 4096 // 256
+
+
 def test_stream_driver_custom_writer_and_bounded_batches(tmp_path, monkeypatch):
     """(a) a writer / reader that only offers the reference's contract (write_block / get_block) gets the per-block
     loop; (b) streams longer than one batch are cut into several launches; both give the same file bytes"""
