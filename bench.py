@@ -356,18 +356,23 @@ def main():
     # The encoders leave every stream in its own slot, described by (bit_offset, nbits) -- the form the decoders read.
     # SURVEY 8d counts the optional left-align / compaction pass with the encode; it is timed here (HIP events, data
     # resident) and reported beside `value`, which it never enters.
-    from stanford_compression_library_amd.backend.models import compact as _compact
+    from stanford_compression_library_amd.backend import models as _m
 
-    _d, _o = _compact(enc)  # warm: the output buffer comes from the allocator's cache afterwards
-    del _d, _o
+    # caller-owned worst-case buffers (scl_streams_compact never waits for the host; the convenience wrapper
+    # models.compact() sizes its output from the bit counts first, which costs a reduction and a host round trip)
+    c_dense = torch.empty(_m.compact_capacity(n_chunks, enc.stride), dtype=torch.uint8, device=dev)
+    c_offs = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
+    c_scratch = torch.empty(_m.compact_scratch_bytes(n_chunks), dtype=torch.uint8, device=dev)
+    _m.compact_into(enc, c_dense, c_offs, c_scratch)  # warm
     cev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     cev[0].record()
-    for _ in range(3):
-        _d, _o = _compact(enc)
-        del _d, _o
+    for _ in range(5):
+        _m.compact_into(enc, c_dense, c_offs, c_scratch)
     cev[1].record()
     torch.cuda.synchronize()
-    compact_ms = cev[0].elapsed_time(cev[1]) / 3
+    compact_ms = cev[0].elapsed_time(cev[1]) / 5
+    assert int(c_offs[-1].item()) == stream_bytes, "compaction total differs from the sum of the stream sizes"
+    del c_dense, c_offs, c_scratch
 
     gather_info = None
     if args.gather:
@@ -401,10 +406,13 @@ def main():
             n_blocks = int(block_offsets(goffs, max(1, (1 << 20) // chunk_len)).numel()) - 1
         del gathered, goffs
         barrier()
-        encode_gather_overlapped(model, sym, world, rank, n_sub=8, comm=comm)  # untimed: buffers come from the cache afterwards
+        from stanford_compression_library_amd.backend.sharded import GatherWorkspace
+
+        ws = GatherWorkspace(model, n_chunks, chunk_len, world, dev)  # caller-owned buffers, streams, pinned counts
+        encode_gather_overlapped(model, sym, world, rank, comm=comm, workspace=ws)  # untimed: connections, allocator
         torch.cuda.synchronize()
         barrier()
-        timings, _ = encode_gather_overlapped(model, sym, world, rank, n_sub=8, comm=comm)
+        timings, _ = encode_gather_overlapped(model, sym, world, rank, comm=comm, workspace=ws)
         barrier()
         t_ov = torch.tensor([timings["overlapped_ms"]], dtype=torch.float64, device="cpu" if shared_gpu or world == 1 else dev)
         if world > 1:
@@ -412,7 +420,7 @@ def main():
         gather_info = {"transport": "rccl (scl_streams_gather_rccl)" if comm is not None else "torch.distributed p2p",
                        "encode_ms": round((ga - g0) * 1e3, 3), "compact_ms": round((g1 - ga) * 1e3, 3),
                        "gather_ms": round((g2 - g1) * 1e3, 3), "sequential_ms": round((g2 - g0) * 1e3, 3),
-                       "overlapped_ms": round(float(t_ov.item()), 3), "sub_batches": 8,
+                       "overlapped_ms": round(float(t_ov.item()), 3), "sub_batches": timings["sub_batches"],
                        "gathered_bytes": int(total), "blocks_1MiB": n_blocks}
         if comm is not None:
             comm.close()

@@ -276,6 +276,11 @@ int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const
  *   scl_streams_gatherv_rccl: n_parts such gathers (a payload and its per-chunk offset table, say) in ONE grouped
  *                             exchange: part p moves h_send_bytes[p] bytes from d_send[p] to the root's d_recv[p]
  *                             + h_rank_offsets[p * (world + 1) + r].
+ *   scl_streams_gather_blocks_rccl: configs[4]'s exchange as one call: a (sub-)batch's dense payload and its
+ *                             n_chunks + 1 record offsets go to the root in one grouped exchange, and the root shifts
+ *                             every rank's offsets by the bytes of the ranks before it (one small kernel on `stream`),
+ *                             so d_recv_offsets [sum chunks + 1] is the offset table a single process would have
+ *                             produced; h_bytes_by_rank / h_chunks_by_rank [world] are the exchanged counts.
  *   Errors: all arguments are checked before anything is posted; after ncclGroupStart the group is closed on every
  *   path (first error recorded, ncclGroupEnd, then return).  A layout that contradicts this rank's own count is
  *   refused on this rank only -- the peers then wait in the exchange, so derive layouts from exchanged counts. */
@@ -290,6 +295,10 @@ int scl_streams_gather_rccl(scl_comm *c, int root, const uint8_t *d_send, uint64
 int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts, const uint8_t *const *d_send,
                              const uint64_t *h_send_bytes, uint8_t *const *d_recv, const uint64_t *h_rank_offsets,
                              void *stream);
+int scl_streams_gather_blocks_rccl(scl_comm *c, int root, const uint8_t *d_payload, uint64_t payload_bytes,
+                                   const uint64_t *d_offsets, uint64_t n_chunks, uint8_t *d_recv_payload,
+                                   uint64_t *d_recv_offsets, const uint64_t *h_bytes_by_rank,
+                                   const uint64_t *h_chunks_by_rank, void *stream);
 
 /* ---- model construction helper (row f3): symbol histogram ------------------------------------------ */
 /* d_counts[256] (uint64) += number of occurrences of every byte value in d_sym[0..n).  The caller zeroes

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "scl_rccl_allgather_u64": (_int, [_vp, _u64, _u64p, _vp]),
     "scl_rccl_allgather_async": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "scl_streams_gather_rccl": (_int, [_vp, _int, _vp, _u64, _vp, _u64p, _vp]),
+    "scl_streams_gather_blocks_rccl": (_int, [_vp, _int, _vp, _u64, _vp, _u64, _vp, _vp, _u64p, _u64p, _vp]),
     "scl_streams_gatherv_rccl": (_int, [_vp, _int, _u32, C.POINTER(_vp), _u64p, C.POINTER(_vp), _u64p, _vp]),
 }
 

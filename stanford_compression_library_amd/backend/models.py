@@ -106,6 +106,9 @@ class _DeviceModel:
         stream replaces it (stream order then guarantees the previous launch is done with the old one)"""
         if not hasattr(self, "_scratch_by_stream"):
             self._scratch_by_stream = {}
+        if isinstance(stream_handle, tuple):  # encode_rows_into: one scratch per sub-batch, kept until replaced
+            self._scratch_by_stream[stream_handle] = scratch
+            return
         self._scratch_by_stream[int(stream_handle or 0)] = scratch
         if scratch is not None and stream_handle:
             import torch
@@ -160,6 +163,26 @@ class _DeviceModel:
             rc = self._fn("encode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
         return out
+
+    def encode_rows_into(self, sym, a: int, b: int, out: EncodedBatch, stream_handle: int):
+        """rows a..b of ``sym`` -> slots a..b of ``out`` on the raw stream handle, by pointer arithmetic (no tensor
+        views: the overlapped pipeline of backend/sharded.py calls this once per sub-batch).  The bit offsets written for
+        those chunks count from SLOT a, i.e. from ``out.data.data_ptr() + a * out.stride``."""
+        import torch
+
+        n_rows, chunk_len = sym.shape
+        assert 0 <= a <= b <= n_rows == out.n_chunks and sym.stride(1) == 1
+        assert sym.stride(0) % 16 == 0 and sym.data_ptr() % 16 == 0, "rows must start on 16-byte boundaries"
+        args = [self._h, sym.data_ptr() + a * sym.stride(0), sym.stride(0), None, chunk_len, b - a,
+                out.data.data_ptr() + a * out.stride, out.stride, out.bit_offset.data_ptr() + 8 * a,
+                out.nbits.data_ptr() + 4 * a, out.status.data_ptr() + 4 * a]
+        if self._needs_scratch:
+            scratch, nbytes = self._scratch(b - a, sym.device)
+            args += [scratch.data_ptr() if scratch is not None else None, nbytes]
+            self._keep_scratch(("rows", a), scratch)
+        with torch.cuda.device(sym.device):
+            rc = self._fn("encode_batch")(*args, stream_handle)
+        _lib.check(rc, f"scl_{self._prefix}_encode_batch")
 
     def alloc_decoded(self, n_chunks: int, chunk_cap: int, device):
         import torch

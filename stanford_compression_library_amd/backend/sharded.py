@@ -23,6 +23,16 @@ from typing import Optional, Tuple
 import numpy as np
 
 
+_TRACE = None  # tools/time_gather.py: list of (label, ms since the pipeline started) when set
+
+
+def _mark(label, t0):
+    if _TRACE is not None:
+        import time
+
+        _TRACE.append((label, (time.perf_counter() - t0) * 1e3))
+
+
 def shard_range(n_units: int, world: int, rank: int) -> Tuple[int, int]:
     """Block-contiguous partition of ``n_units`` (chunks or blocks) over ``world`` ranks; the first
     ``n_units % world`` ranks get one extra unit."""
@@ -215,60 +225,117 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
     return total
 
 
-def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: int = 8, dst: int = 0,
-                             comm: Optional[RcclGather] = None, framed: bool = False):
+class GatherWorkspace:
+    """Everything :func:`encode_gather_overlapped` needs that does not depend on the data: the two streams, one
+    worst-case buffer per kind for the whole shard (sub-batch i owns a slice of each), the pinned read-back area for
+    the counts.  Build it once per (model, shard shape) and hand it to every call -- the pipeline itself then allocates
+    nothing but the root's exactly-sized receive buffers."""
+
+    def __init__(self, model, n_chunks: int, chunk_len: int, world: int, device, n_sub: Optional[int] = None,
+                 framed: bool = False):
+        import torch
+
+        from .models import compact_capacity, compact_scratch_bytes
+
+        n_sub = default_sub_batches(n_chunks) if n_sub is None else int(n_sub)
+        self.n_chunks, self.chunk_len, self.world, self.n_sub, self.framed = n_chunks, chunk_len, world, n_sub, framed
+        self.device = dev = device
+        self.bounds = b = [n_chunks * i // n_sub for i in range(n_sub + 1)]
+        self.sizes = [b[i + 1] - b[i] for i in range(n_sub)]
+        self.comp, self.comm_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.stride = model.slot_bytes(chunk_len)
+        self.enc = model.alloc_encoded(n_chunks, chunk_len, dev, self.stride)
+        self.caps = [(compact_capacity(n, self.stride, framed) + 255) // 256 * 256 for n in self.sizes]
+        self.cap_base = [0]
+        for c in self.caps:
+            self.cap_base.append(self.cap_base[-1] + c)
+        self.dense = torch.empty(self.cap_base[-1], dtype=torch.uint8, device=dev)
+        # offsets of sub-batch i: entries [p_i, p_i + n_i] (n_i + 1 of them), then ONE slot holding n_i, so that
+        # {payload bytes, chunks} are two consecutive u64 -- the all-gather's input, no copy kernel
+        self.pos = [b[i] + 2 * i for i in range(n_sub)]
+        offs = torch.zeros(n_chunks + 2 * n_sub, dtype=torch.int64)
+        for i in range(n_sub):
+            offs[self.pos[i] + self.sizes[i] + 1] = self.sizes[i]
+        self.offs = offs.to(dev)
+        self.scr = (compact_scratch_bytes(max(self.sizes + [1])) + 255) // 256 * 256
+        self.scratch = torch.empty(self.scr * n_sub, dtype=torch.uint8, device=dev)
+        self.all_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, device=dev)
+        self.h_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, pin_memory=True)
+        torch.cuda.current_stream(dev).synchronize()
+
+    def matches(self, model, sym, world, n_sub, framed) -> bool:
+        return (tuple(sym.shape) == (self.n_chunks, self.chunk_len) and sym.device == self.device and world == self.world
+                and n_sub == self.n_sub and framed == self.framed and model.slot_bytes(self.chunk_len) == self.stride)
+
+
+def default_sub_batches(n_chunks: int) -> int:
+    """sub-batches of at least 128 Ki chunks (two waves per SIMD on 256 CUs: below that the lane-per-chunk encoders run
+    at half their rate, profiles/r02_bench_config2_64Ki.json), at most 4"""
+    return max(1, min(4, int(n_chunks) // (128 * 1024)))
+
+
+def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: Optional[int] = None, dst: int = 0,
+                             comm: Optional[RcclGather] = None, framed: bool = False,
+                             workspace: Optional[GatherWorkspace] = None):
     """configs[4] end to end for this rank's shard ``sym`` (uint8 [n_chunks, chunk_len] on the device): the shard is
     cut into ``n_sub`` sub-batches; ALL of them are queued on the compute stream up front (encode + compaction into
-    caller-owned worst-case buffers: nothing there ever waits for the host), and sub-batch i travels to ``dst`` on the
-    communication stream while the later ones are still being coded.
+    the workspace's worst-case buffers: nothing there ever waits for the host), and sub-batch i travels to ``dst`` on
+    the communication stream while the later ones are still being coded.
 
     Host traffic per sub-batch with an :class:`RcclGather`: ONE asynchronous device-to-device all-gather carrying
-    ``{payload bytes, chunks}`` of every rank, ONE wait on the event behind its read-back (the root must know the
-    counts to post its receives), ONE grouped send / receive that moves the payload and the per-chunk offset table
-    together.  No ``.item()``, no stream synchronisation inside the loop.  The all-gather of sub-batch i + 1 is queued
-    BEFORE the exchange of sub-batch i, so its counts are already on the host when the exchange of i ends and the
-    communication stream never idles on a host round trip.  Without an RcclGather (gloo in the CPU tests, or a single
-    process) the per-sub-batch exchange goes through :func:`gather_streams_to_root`.
+    ``{payload bytes, chunks}`` of every rank (read straight out of the compaction's offset table), ONE wait on the event
+    behind its read-back (the root must know the counts to post its receives), ONE call that moves the payload and the
+    per-chunk offset table in one grouped send / receive and globalises the offsets on the root
+    (``scl_streams_gather_blocks_rccl``).  No ``.item()``, no stream synchronisation inside the loop.  The all-gather of
+    sub-batch i + 1 is queued BEFORE the exchange of sub-batch i, so its counts are already on the host when the
+    exchange of i ends and the communication stream never idles on a host round trip.  Default: sub-batches of at least
+    128 Ki chunks, at most 4 (``default_sub_batches``) -- smaller ones leave the encoder one wave per SIMD, and over
+    xGMI half a 1 GiB shard (~0.5 GiB of streams, ~3 ms per link) already hides the ~0.5 ms it takes to code the
+    other half; every sub-batch costs the host ~0.1 ms (profiles/r03_gather_host_trace.txt).
+    Without an RcclGather (gloo in the CPU tests, or a single process) the per-sub-batch exchange goes through
+    :func:`gather_streams_to_root`.  ``workspace``: a :class:`GatherWorkspace` to reuse (else one is built, untimed).
 
     Returns (timings dict, on the root a list of per-sub-batch (bytes, global_offsets) pairs in sub-batch order -- the
-    root's buffer for sub-batch i holds the ranks' sub-batch-i payloads in rank order --, None elsewhere).
+    root's buffer for sub-batch i holds the ranks' sub-batch-i payloads in rank order --, None elsewhere).  The pairs
+    of a non-RCCL run are views of the workspace: valid until its next use.
     """
     import time
 
     import torch
 
-    from .models import compact_capacity, compact_into, compact_scratch_bytes
+    from . import lib as _lib
 
+    L = _lib.load()
     dev = sym.device
     n_chunks, chunk_len = sym.shape
-    bounds = [n_chunks * i // n_sub for i in range(n_sub + 1)]
-    comp, comm_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    n_sub = default_sub_batches(n_chunks) if n_sub is None else int(n_sub)
+    if n_chunks and (sym.stride(0) % 16 or sym.data_ptr() % 16):
+        sym = torch.nn.functional.pad(sym, (0, -chunk_len % 16))[:, :chunk_len]  # rows on 16-byte boundaries
+    ws = workspace
+    if ws is None or not ws.matches(model, sym, world, n_sub, framed):
+        ws = GatherWorkspace(model, n_chunks, chunk_len, world, dev, n_sub, framed)
+    bounds, pos, enc, stride = ws.bounds, ws.pos, ws.enc, ws.stride
+    comp, comm_stream = ws.comp, ws.comm_stream
+    mode = _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE
+    t0 = time.perf_counter()
     comp.wait_stream(torch.cuda.current_stream(dev))
     comm_stream.wait_stream(torch.cuda.current_stream(dev))
-    stride = model.slot_bytes(chunk_len)
-    # {payload bytes, chunks} per sub-batch: column 1 is known now, column 0 is written by the compute stream
-    h_counts = torch.tensor([[0, bounds[i + 1] - bounds[i]] for i in range(n_sub)], dtype=torch.int64)
-    meta = h_counts.to(dev)
-    all_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, device=dev)
-    h_meta = torch.empty((n_sub, world, 2), dtype=torch.int64, pin_memory=True)
-    t0 = time.perf_counter()
 
     # ---- compute stream: everything, now ----------------------------------------------------------------------
-    jobs = []
-    with torch.cuda.stream(comp):
+    done = []
+    with torch.cuda.device(dev):
         for i in range(n_sub):
             a, b = bounds[i], bounds[i + 1]
-            enc = model.encode_batch(sym[a:b], stream=comp.cuda_stream, out_stride=stride)
-            dense = torch.empty(compact_capacity(b - a, stride, framed), dtype=torch.uint8, device=dev)
-            offs = torch.empty(b - a + 1, dtype=torch.int64, device=dev)
-            scratch = torch.empty(compact_scratch_bytes(b - a), dtype=torch.uint8, device=dev)
-            compact_into(enc, dense, offs, scratch, framed=framed, stream=comp)
-            meta[i, 0:1].copy_(offs[b - a:], non_blocking=True)
+            model.encode_rows_into(sym, a, b, enc, comp.cuda_stream)
+            rc = L.scl_streams_compact(enc.data.data_ptr() + a * stride, enc.bit_offset.data_ptr() + 8 * a,
+                                       enc.nbits.data_ptr() + 4 * a, b - a, mode, ws.dense.data_ptr() + ws.cap_base[i],
+                                       ws.caps[i], ws.offs.data_ptr() + 8 * pos[i], ws.scratch.data_ptr() + ws.scr * i,
+                                       comp.cuda_stream)
+            _lib.check(rc, "scl_streams_compact")
             ev = torch.cuda.Event()
             ev.record(comp)
-            for t in (dense, offs, meta):
-                t.record_stream(comm_stream)
-            jobs.append(dict(enc=enc, dense=dense, offs=offs, scratch=scratch, ev=ev, n=b - a))
+            done.append(ev)
+            _mark(f"compute {i} queued", t0)
 
     results = []
     if comm is not None:
@@ -276,54 +343,59 @@ def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: int = 8, 
         sizes_ready = []
 
         def queue_sizes(i):
-            comm_stream.wait_event(jobs[i]["ev"])
+            comm_stream.wait_event(done[i])
+            with torch.cuda.device(dev):
+                rc = L.scl_rccl_allgather_async(comm._h, ws.offs.data_ptr() + 8 * (pos[i] + ws.sizes[i]),
+                                                ws.all_meta[i].data_ptr(), 2, comm_stream.cuda_stream)
+            _lib.check(rc, "scl_rccl_allgather_async")
             with torch.cuda.stream(comm_stream):
-                comm.allgather_async(meta[i], all_meta[i], stream=comm_stream)
-                h_meta[i].copy_(all_meta[i], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
+                ws.h_meta[i].copy_(ws.all_meta[i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(comm_stream)
             sizes_ready.append(ev)
 
         queue_sizes(0)
+        u64p = C.POINTER(C.c_uint64)
         for i in range(n_sub):
             if i + 1 < n_sub:
                 queue_sizes(i + 1)
+            _mark(f"sizes {i + 1} queued", t0)
             sizes_ready[i].synchronize()  # the one host wait of this sub-batch: the counts of every rank
-            counts = h_meta[i].numpy()
-            base = np.concatenate([[0], np.cumsum(counts[:, 0])]).astype(np.uint64)
-            cbase = np.concatenate([[0], np.cumsum(counts[:, 1])]).astype(np.uint64)
-            job = jobs[i]
+            _mark(f"sizes {i} on host", t0)
+            counts = ws.h_meta[i].numpy().astype(np.uint64)
+            nbytes_r, chunks_r = np.ascontiguousarray(counts[:, 0]), np.ascontiguousarray(counts[:, 1])
+            total = int(nbytes_r.sum())
             out = goffs = None
-            with torch.cuda.stream(comm_stream):
-                if rank == dst:
-                    out = torch.empty(max(int(base[-1]), 1), dtype=torch.uint8, device=dev)
-                    goffs = torch.empty(int(cbase[-1]) + 1, dtype=torch.int64, device=dev)
-                comm.gatherv([(job["dense"], int(counts[rank, 0]), base, out),
-                              (job["offs"].view(torch.uint8), 8 * job["n"], 8 * cbase,
-                               goffs.view(torch.uint8) if goffs is not None else None)], root=dst, stream=comm_stream)
-                if rank == dst:
-                    # offsets arrive relative to their own rank's buffer: one add of the per-chunk rank base
-                    if world > 1:
-                        shift = torch.from_numpy(np.repeat(base[:-1].astype(np.int64), counts[:, 1])).to(dev, non_blocking=True)
-                        goffs[:-1] += shift
-                    goffs[-1] = int(base[-1])
-                    out = out[:int(base[-1])]
-            results.append((int(base[-1]), out, goffs))
+            if rank == dst:
+                with torch.cuda.stream(comm_stream):
+                    out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+                    goffs = torch.empty(int(chunks_r.sum()) + 1, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.scl_streams_gather_blocks_rccl(
+                    comm._h, int(dst), ws.dense.data_ptr() + ws.cap_base[i], int(nbytes_r[rank]),
+                    ws.offs.data_ptr() + 8 * pos[i], ws.sizes[i], out.data_ptr() if out is not None else None,
+                    goffs.data_ptr() if goffs is not None else None, nbytes_r.ctypes.data_as(u64p),
+                    chunks_r.ctypes.data_as(u64p), comm_stream.cuda_stream)
+            _lib.check(rc, "scl_streams_gather_blocks_rccl")
+            results.append((total, out[:total] if out is not None else None, goffs))
+            _mark(f"exchange {i} queued", t0)
     else:
         # ---- any torch.distributed backend (gloo in the tests) / a single process ---------------------------
         for i in range(n_sub):
-            job = jobs[i]
-            job["ev"].synchronize()
-            comm_stream.wait_event(job["ev"])
+            dense = ws.dense[ws.cap_base[i]:ws.cap_base[i] + ws.caps[i]]
+            offs = ws.offs[pos[i]:pos[i] + ws.sizes[i] + 1]
+            done[i].synchronize()
+            comm_stream.wait_event(done[i])
             with torch.cuda.stream(comm_stream):
                 if world > 1:
-                    results.append(gather_streams_to_root(job["dense"], job["offs"], world, rank, dev, dst, return_data=True))
+                    results.append(gather_streams_to_root(dense, offs, world, rank, dev, dst, return_data=True))
                 else:
-                    n = int(job["offs"][-1].item())
-                    results.append((n, job["dense"][:n], job["offs"]))
+                    n = int(offs[-1].item())
+                    results.append((n, dense[:n], offs))
     comm_stream.synchronize()
     comp.synchronize()
     total_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.current_stream(dev).wait_stream(comm_stream)
     timings = {"overlapped_ms": round(total_ms, 3), "sub_batches": n_sub,
                "gathered_bytes": int(sum(r[0] for r in results))}
     return timings, ([(r[1], r[2]) for r in results] if rank == dst else None)

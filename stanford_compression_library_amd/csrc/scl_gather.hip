@@ -165,6 +165,11 @@ extern "C" int scl_rccl_allgather_u64(scl_comm *c, uint64_t value, uint64_t *h_o
 extern "C" int scl_rccl_allgather_async(scl_comm *c, const uint64_t *d_in, uint64_t *d_out, uint64_t n_u64, void *stream) {
     SCL_REQUIRE(c && d_in && d_out && n_u64 >= 1, "rccl_allgather_async: bad arguments");
     if (int rc = scl_check_device(c->device, "rccl_allgather_async")) return rc;
+    if (c->world == 1) {  // a one-rank all-gather is a copy: no collective kernel for it
+        if (d_in != d_out)
+            SCL_HIP_TRY(hipMemcpyAsync(d_out, d_in, n_u64 * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return SCL_OK;
+    }
     SCL_RCCL_TRY(g_rccl.AllGather(d_in, d_out, n_u64, scl_ncclUint64, c->comm, (hipStream_t)stream));
     return SCL_OK;
 }
@@ -199,10 +204,11 @@ extern "C" int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts,
                     "streams_gatherv_rccl: the root needs a receive buffer for part %u", p);
     }
     // one grouped exchange: every non-root rank sends its parts, the root posts one receive per sender and part
-    SCL_RCCL_TRY(g_rccl.GroupStart());
+    // (a one-rank communicator has nothing to post: only the root's own copies below)
     ncclResult_t first = 0;
     const char *what = "";
-    for (u32 p = 0; p < n_parts && first == 0; ++p) {
+    if (W > 1) SCL_RCCL_TRY(g_rccl.GroupStart());
+    for (u32 p = 0; p < n_parts && first == 0 && W > 1; ++p) {
         const u64 *offs = h_rank_offsets + (u64)p * (W + 1);
         if (c->rank == root) {
             for (int r = 0; r < W && first == 0; ++r) {
@@ -217,7 +223,7 @@ extern "C" int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts,
             what = "ncclSend";
         }
     }
-    const ncclResult_t end = g_rccl.GroupEnd();  // always: never leave the thread's group open
+    const ncclResult_t end = W > 1 ? g_rccl.GroupEnd() : 0;  // always: never leave the thread's group open
     if (first != 0 || end != 0) {
         scl_set_error("streams_gatherv_rccl: %s failed: %s", first != 0 ? what : "ncclGroupEnd",
                       g_rccl.GetErrorString(first != 0 ? first : end));
@@ -228,6 +234,83 @@ extern "C" int scl_streams_gatherv_rccl(scl_comm *c, int root, uint32_t n_parts,
             if (h_send_bytes[p])
                 SCL_HIP_TRY(hipMemcpyAsync(d_recv[p] + h_rank_offsets[(u64)p * (W + 1) + root], d_send[p], h_send_bytes[p],
                                            hipMemcpyDeviceToDevice, st));
+    return SCL_OK;
+}
+
+// configs[4]'s exchange as ONE call: a sub-batch's dense payload AND its per-chunk offset table travel to the root in
+// one grouped exchange, and the root turns the per-rank offset tables into the GLOBAL one (rank r's entries shifted by
+// the bytes of the ranks before it, last entry = grand total) with one small kernel on the same stream -- so the
+// root ends up with exactly what a single process would have produced for the ranks' chunks in rank order.
+//   d_payload / payload_bytes : this rank's dense streams (scl_streams_compact output)
+//   d_offsets                 : this rank's n_chunks + 1 record offsets (u64, the compaction's offset table)
+//   h_bytes_by_rank / h_chunks_by_rank [world] : every rank's counts, as exchanged by scl_rccl_allgather_*
+//   d_recv_payload [sum bytes], d_recv_offsets [sum chunks + 1] : on the root only
+struct GatherFix {
+    u64 cbase[65];  // exclusive prefix of the chunk counts
+    u64 bbase[65];  // exclusive prefix of the byte counts
+    u32 world;
+};
+__global__ void gather_fix_offsets(u64 *__restrict__ goffs, GatherFix f) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n = f.cbase[f.world];
+    if (idx > n) return;
+    if (idx == n) {
+        goffs[idx] = f.bbase[f.world];
+        return;
+    }
+    u32 r = 0;
+    while (r + 1 < f.world && idx >= f.cbase[r + 1]) ++r;
+    if (r) goffs[idx] += f.bbase[r];
+}
+
+extern "C" int scl_streams_gather_blocks_rccl(scl_comm *c, int root, const uint8_t *d_payload, uint64_t payload_bytes,
+                                              const uint64_t *d_offsets, uint64_t n_chunks, uint8_t *d_recv_payload,
+                                              uint64_t *d_recv_offsets, const uint64_t *h_bytes_by_rank,
+                                              const uint64_t *h_chunks_by_rank, void *stream) {
+    SCL_REQUIRE(c && h_bytes_by_rank && h_chunks_by_rank && root >= 0 && root < c->world && c->world <= 64,
+                "streams_gather_blocks_rccl: bad arguments (at most 64 ranks)");
+    const int W = c->world;
+    SCL_REQUIRE(h_bytes_by_rank[c->rank] == payload_bytes && h_chunks_by_rank[c->rank] == n_chunks,
+                "streams_gather_blocks_rccl: rank %d's own counts (%llu bytes, %llu chunks) differ from the exchanged ones",
+                c->rank, (unsigned long long)payload_bytes, (unsigned long long)n_chunks);
+    SCL_REQUIRE(d_offsets || n_chunks == 0, "streams_gather_blocks_rccl: null offset table");
+    GatherFix f;
+    u64 offs[2][65];
+    f.world = (u32)W;
+    f.cbase[0] = f.bbase[0] = 0;
+    for (int r = 0; r < W; ++r) {
+        f.cbase[r + 1] = f.cbase[r] + h_chunks_by_rank[r];
+        f.bbase[r + 1] = f.bbase[r] + h_bytes_by_rank[r];
+    }
+    for (int r = 0; r <= W; ++r) {
+        offs[0][r] = f.bbase[r];
+        offs[1][r] = 8 * f.cbase[r];
+    }
+    if (W == 1) {  // nothing to exchange: two device copies (the offset table is already global)
+        hipStream_t st = (hipStream_t)stream;
+        if (int rc = scl_check_device(c->device, "streams_gather_blocks_rccl")) return rc;
+        SCL_REQUIRE((d_recv_payload || payload_bytes == 0) && d_recv_offsets, "streams_gather_blocks_rccl: the root needs receive buffers");
+        if (payload_bytes)
+            SCL_HIP_TRY(hipMemcpyAsync(d_recv_payload, d_payload, payload_bytes, hipMemcpyDeviceToDevice, st));
+        SCL_HIP_TRY(hipMemcpyAsync(d_recv_offsets, d_offsets, 8 * (n_chunks + 1), hipMemcpyDeviceToDevice, st));
+        return SCL_OK;
+    }
+    // two parts, laid out [part][world + 1]
+    u64 flat[2 * 65];
+    for (int r = 0; r <= W; ++r) {
+        flat[r] = offs[0][r];
+        flat[(W + 1) + r] = offs[1][r];
+    }
+    const uint8_t *send[2] = {d_payload, (const uint8_t *)d_offsets};
+    const u64 nbytes[2] = {payload_bytes, 8 * n_chunks};
+    uint8_t *recv[2] = {d_recv_payload, (uint8_t *)d_recv_offsets};
+    SCL_REQUIRE(c->rank != root || d_recv_offsets, "streams_gather_blocks_rccl: the root needs receive buffers");
+    if (int rc = scl_streams_gatherv_rccl(c, root, 2, send, nbytes, recv, flat, stream)) return rc;
+    if (c->rank == root) {
+        const u64 n = f.cbase[W] + 1;
+        hipLaunchKernelGGL(gather_fix_offsets, dim3((u32)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_recv_offsets, f);
+        SCL_HIP_TRY(hipGetLastError());
+    }
     return SCL_OK;
 }
 
