@@ -30,6 +30,8 @@
 //  * Encoder software pipeline: the model reads of symbol i+1 are in flight while symbol i is coded; words go
 //    straight to the slot (4-byte stores, L2 merges them); symbols arrive four per 32-bit load, one word ahead,
 //    the load unconditional so that it is not waited for at once.
+#include <stdlib.h>
+
 #include "scl_aec_internal.h"
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
@@ -405,6 +407,17 @@ static AecFastDev aec_fast_dev(const scl_aec_model *m) {
 void aec_fast_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
                             u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
                             u32 *d_status, hipStream_t st) {
+    // round 3: the two-role encoder (scl_aec_split.hip) serves every batch; SCL_AEC_ENC=lane keeps the one-lane-per-
+    // chunk kernel below for A/B timing and as a second implementation the tests compare against
+    static const bool lane_kernel = [] {
+        const char *e = getenv("SCL_AEC_ENC");
+        return e && (e[0] == 'l' || e[0] == 'L');
+    }();
+    if (!lane_kernel) {
+        (void)aec_split_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                      d_out_bit_offset, d_out_nbits, d_status, st);
+        return;
+    }
     const u32 blocks = (u32)((n_chunks + AF_THREADS - 1) / AF_THREADS);
     if (m->dev.k == 1)
         hipLaunchKernelGGL(aec_fast_encode_kernel<true>, dim3(blocks), dim3(AF_THREADS), 0, st, aec_fast_dev(m),

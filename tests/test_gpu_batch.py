@@ -592,8 +592,7 @@ def test_tuned_kernels_full_occupancy_stress(mode, dev):
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5001, device=dev)
         model = models.AecModel(1, [1] * 256, 256, 0, 1 << 30, 32, 32)
     else:
-        base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(256)])
-        sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 256, 1).contiguous()
+        sym = bench_data.markov1_chunks_device(16, n_chunks, chunk_len, seed=900, device=dev)  # all chunks distinct
         model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
     if isinstance(model, models.AecModel):
         assert model.fast_path(chunk_len)
