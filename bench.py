@@ -41,8 +41,9 @@ def parse_args():
                     help="t256: Dirichlet table M=4096; uniform: f=16, M=4096; uniform1: f=1, M=256 (configs[2])")
     ap.add_argument("--coder", choices=["rans", "tans", "range", "aec"], default="rans")
     ap.add_argument("--aec-K", type=int, default=16, help="alphabet of the order-1 adaptive arithmetic coder (configs[3])")
-    ap.add_argument("--aec-model", choices=["order1", "fixed"], default="order1",
-                    help="arithmetic coder: order-1 adaptive model on a Markov-1 source, or FixedFreqModel(--table) on i.i.d. symbols")
+    ap.add_argument("--aec-model", choices=["order1", "fixed", "iid"], default="order1",
+                    help="arithmetic coder: order-1 adaptive model on a Markov-1 source, FixedFreqModel(--table) on i.i.d. "
+                         "symbols, or AdaptiveIIDFreqModel (all-ones start, 256 symbols) on the same i.i.d. symbols")
     ap.add_argument("--num-bits-out", type=int, default=1, help="rANS NUM_BITS_OUT (reference default 1)")
     ap.add_argument("--range-factor", type=int, default=1 << 16, help="rANS RANGE_FACTOR (reference default 2^16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +89,9 @@ def make_model(args, freq):
     if args.coder == "aec" and args.aec_model == "fixed":
         return (models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
                 dict(PRECISION=32, model=f"FixedFreqModel({args.table})"))
+    if args.coder == "aec" and args.aec_model == "iid":
+        return (models.AecModel(1, [1] * int(freq.size), int(freq.size), 0, 1 << 30, 32, 32),
+                dict(PRECISION=32, model=f"AdaptiveIIDFreqModel(all ones, K={int(freq.size)}) on {args.table} symbols"))
     if args.coder == "aec":
         K = args.aec_K
         return (models.AecModel(backend_lib_consts()["MODEL_ORDERK"], None, K, 1, 1 << 30, 32, 32),
@@ -153,6 +157,10 @@ def cpu_baseline(args, freq, sym_dev, enc, target_seconds=10.0):
     nbytes = sym.size
     return {
         "value": round(nbytes / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": len(parts), "kind": "port",
+        # which baseline this is: a C restatement of the reference's algorithm -- NOT the reference's speed (the reference is
+        # pure Python and runs ~25 000 x slower per core: cpu_baseline_restatement below, calibrated in BASELINE.md 4.2)
+        "kind_note": "C port of the algorithm (oracle/scl_oracle.c), a 'reasonable CPU' line; the reference itself is pure "
+                     "Python: see cpu_baseline_restatement for its speed",
         "sample": f"{n} chunks x {sym.shape[1]} B of the same batch ({nbytes / 2**20:.1f} MiB), oracle/scl_oracle.c "
                   f"-O2, {len(parts)} threads (one per host core), encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode "
                   f"{nbytes / (t2 - t1) / 1e6:.2f} MB/s aggregate; one thread alone: {single_thread:.2f} MB/s round trip",
@@ -227,14 +235,30 @@ def rocprof_kernel_names(args, freq):
     return f"{args.coder}_encode", f"{args.coder}_decode"
 
 
-def load_traffic_note():
-    """HBM traffic per launch measured with rocprofv3 PMC passes (committed under profiles/)."""
+def traffic_key(args, freq):
+    """what a PMC pass must have been taken on to be quoted for this run (tools/make_traffic_json.py stores it)"""
+    key = {"coder": args.coder, "chunks": args.chunks, "chunk_len": args.chunk_len}
+    if args.coder == "aec" and args.aec_model == "order1":
+        key.update(model="order1", K=args.aec_K)
+    else:
+        key.update(table=args.table, source=args.source, M=int(freq.sum()))
+        if args.coder == "rans":
+            key.update(num_bits_out=args.num_bits_out, range_factor=args.range_factor)
+        if args.coder == "aec":
+            key.update(model=args.aec_model)
+    return key
+
+
+def load_traffic_note(key):
+    """HBM traffic per launch measured with rocprofv3 PMC passes (committed under profiles/traffic.json): the entry
+    taken on exactly this workload, or None -- a pass is never attached to another workload."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path))
-        except Exception:
-            return None
+    try:
+        for e in json.load(open(path)).get("entries", []):
+            if e.get("key") == key:
+                return e
+    except Exception:
+        pass
     return None
 
 
@@ -272,7 +296,7 @@ def main():
     freq = {"t256": bench_data.t256_table, "uniform": bench_data.uniform256_table,
             "uniform1": lambda: np.ones(256, dtype=np.int64)}[args.table]()
     n_chunks, chunk_len = args.chunks, args.chunk_len
-    static_model = args.coder != "aec" or args.aec_model == "fixed"
+    static_model = args.coder != "aec" or args.aec_model in ("fixed", "iid")
     source_note = f"256-symbol static table {args.table} (M={int(freq.sum())}), i.i.d. symbols p=f/M"
     if not static_model:
         # configs[3]: Markov-1 source (S4 of SURVEY 8d), every chunk its own chain, generated on the device: the whole
@@ -428,17 +452,12 @@ def main():
     if rank == 0:
         total_bytes = in_bytes * world
         value = total_bytes * args.steps / elapsed / 1e6
-        traffic = load_traffic_note()
-        # the PMC passes were taken on one workload only: never attach them to another one
-        w = (traffic or {}).get("workload", {})
-        if not (w.get("coder") == args.coder and w.get("table") == args.table and w.get("chunks") == args.chunks
-                and w.get("chunk_len") == args.chunk_len and args.num_bits_out == 1
-                and args.range_factor == 1 << 16):
-            traffic = None
+        tkey = traffic_key(args, freq)
+        traffic = load_traffic_note(tkey)
 
         def roof(ms, name, kernel):
             gbs = alg_bytes / (ms * 1e-3) / 1e9
-            t = traffic.get(name) if traffic else None
+            t = traffic.get(name.split("_")[-1]) if traffic else None
             return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": t,
                     # not a live counter: HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
@@ -468,7 +487,7 @@ def main():
             "decode_MBps": round(total_bytes / (dec_ms * 1e-3) / 1e6, 2),
             "roofline": r_enc if enc_ms >= dec_ms else r_dec,
             "roofline_encode": r_enc, "roofline_decode": r_dec,
-            "round_trip_verified": True,
+            "round_trip_verified": True, "traffic_key": tkey,
             "dense_output": {"compact_ms": round(compact_ms, 4), "compacted_bytes": stream_bytes,
                              "value_incl_compaction_MBps":
                                  round(total_bytes / ((enc_ms + compact_ms + dec_ms) * 1e-3) / 1e6, 2)},

@@ -10,6 +10,7 @@ Everything raises ``SclHipError`` when the HIP library or a device is missing: n
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -23,6 +24,27 @@ def _freq_array(freq_list) -> np.ndarray:
     if arr.size and (arr.min() < 0 or arr.max() >= (1 << 32)):
         raise AssertionError("frequencies must fit an unsigned 32-bit integer")
     return arr.astype(np.uint32)
+
+
+class _any_parameter:
+    """context manager: the library's tuned kernels are kept out while it is active (csrc/scl_core.hip reads
+    ``SCL_ANY_PARAMETER_KERNELS`` at every batch call)"""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            self.prev = os.environ.get("SCL_ANY_PARAMETER_KERNELS")
+            os.environ["SCL_ANY_PARAMETER_KERNELS"] = "1"
+
+    def __exit__(self, *exc):
+        if self.on:
+            if self.prev is None:
+                os.environ.pop("SCL_ANY_PARAMETER_KERNELS", None)
+            else:
+                os.environ["SCL_ANY_PARAMETER_KERNELS"] = self.prev
+        return False
 
 
 @dataclass
@@ -131,22 +153,13 @@ class _DeviceModel:
                      out: Optional[EncodedBatch] = None, any_parameter_kernels: bool = False) -> EncodedBatch:
         """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks].
         ``out`` reuses buffers from :meth:`alloc_encoded`.  ``any_parameter_kernels`` (tests, stress tools) keeps
-        the tuned kernels out by handing the library rows that do not start on 16-byte boundaries."""
+        the tuned kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call)."""
         import torch
 
         assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
         dev = sym.device
-        if any_parameter_kernels and n_chunks:
-            odd = torch.empty((n_chunks, (chunk_len + 15) // 16 * 16 + 8), dtype=torch.uint8, device=dev)
-            odd[:, :chunk_len] = sym
-            sym = odd[:, :chunk_len]
-        elif n_chunks and (sym.stride(0) % 16 or sym.data_ptr() % 16):
-            # the tuned kernels read whole 16-byte blocks / 128-byte lines: rows that do not start on 16-byte
-            # boundaries would silently get the any-parameter kernels (20-50x slower), so re-lay them out once
-            padded = torch.empty((n_chunks, (chunk_len + 15) // 16 * 16), dtype=torch.uint8, device=dev)
-            padded[:, :chunk_len] = sym
-            sym = padded[:, :chunk_len]
+        # rows that do not start on 16-byte boundaries are re-laid INSIDE the library (RowRelay, csrc/scl_core.hip)
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride)
         assert out.n_chunks == n_chunks
@@ -159,7 +172,8 @@ class _DeviceModel:
             scratch, nbytes = self._scratch(n_chunks, dev)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
             self._keep_scratch(st, scratch)
-        with torch.cuda.device(dev):  # the library launches on the CURRENT device and checks it is the model's
+        with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
+            # the library launches on the CURRENT device and checks it is the model's
             rc = self._fn("encode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
         return out
@@ -197,15 +211,13 @@ class _DeviceModel:
                      any_parameter_kernels: bool = False):
         """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device.
         ``out`` reuses buffers from :meth:`alloc_decoded`.  ``any_parameter_kernels`` (tests) keeps the tuned
-        kernels out by giving the output rows a stride that is not a multiple of 16."""
+        kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call)."""
         import torch
 
         assert data.is_cuda and data.dtype == torch.uint8
         n_chunks = int(bit_offset.numel())
         dev = data.device
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
-        if any_parameter_kernels:
-            sym = torch.empty((n_chunks, (int(chunk_cap) + 15) // 16 * 16 + 8), dtype=torch.uint8, device=dev)
         out_stride = sym.stride(0)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         args = [self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
@@ -214,7 +226,7 @@ class _DeviceModel:
             scratch, nbytes = self._scratch(n_chunks, dev)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
             self._keep_scratch(st, scratch)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
             rc = self._fn("decode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_decode_batch")
         return sym[:, :chunk_cap], lens, used, status

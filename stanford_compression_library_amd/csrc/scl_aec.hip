@@ -552,8 +552,13 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "aec_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
+    if (tuned && (aec_fast_ok(m, chunk_len) || aec_iid_ok(m, chunk_len) || aec_static_ok(m)) &&
+        out_stride >= scl_aec_slot_bytes(m, chunk_len))
+        if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, st)) return rc_r;
     // small-alphabet adaptive models: cumulative context rows in LDS, closed-form renormalisation (scl_aec_fast.hip)
-    if (aec_fast_ok(m, chunk_len) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+    if (tuned && aec_fast_ok(m, chunk_len) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
         sym_stride >= scl_round_up(chunk_len, 16) && (out_stride & 63) == 0 &&
         out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
         aec_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
@@ -562,7 +567,7 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         return SCL_OK;
     }
     // adaptive i.i.d. model on a large alphabet: two-level cumulative table per lane in LDS (scl_aec_iid.hip)
-    if (aec_iid_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
+    if (tuned && aec_iid_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
         sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
         aec_iid_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                               d_out_nbits, d_status, st);
@@ -570,7 +575,7 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         return SCL_OK;
     }
     // static model: shared table in LDS, line-granular I/O (scl_aec_static.hip)
-    if (aec_static_ok(m) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 && (out_stride & 15) == 0 &&
+    if (tuned && aec_static_ok(m) && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 && (out_stride & 15) == 0 &&
         out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
         aec_static_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                  d_out_bit_offset, d_out_nbits, d_status, st);
@@ -606,26 +611,30 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (aec_fast_ok(m, out_cap) && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
+    if (tuned && (aec_fast_ok(m, out_cap) || aec_iid_ok(m, out_cap) || aec_static_ok(m)) && ((uintptr_t)d_in & 15) == 0)
+        if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, st)) return rc_r;
+    if (tuned && aec_fast_ok(m, out_cap) && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
         (out_stride & 15) == 0 && out_stride >= scl_round_up(out_cap, 16)) {
         aec_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return SCL_OK;
+        return relay.out_end();
     }
-    if (aec_iid_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
+    if (tuned && aec_iid_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
         out_stride >= scl_round_up(out_cap, 4)) {
         aec_iid_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                               out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return SCL_OK;
+        return relay.out_end();
     }
-    if (aec_static_ok(m) && ((uintptr_t)d_in & 15) == 0 && in_size_bytes < (1ull << 34) &&
+    if (tuned && aec_static_ok(m) && ((uintptr_t)d_in & 15) == 0 && in_size_bytes < (1ull << 34) &&
         ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0 && out_stride >= out_cap) {
         aec_static_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                  out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return SCL_OK;
+        return relay.out_end();
     }
     if (!aec_use_lds(m, out_cap)) {
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
@@ -642,7 +651,7 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                            d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
     SCL_HIP_TRY(hipGetLastError());
-    return SCL_OK;
+    return relay.out_end();
 }
 
 // ---- coder state carried across blocks (quirk Q4) -----------------------------------------------------------

@@ -56,6 +56,27 @@ static inline u64 scl_round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 int scl_current_device(void);
 int scl_check_device(int model_device, const char *what);
 
+// Rows the tuned kernels cannot take as they are -- symbol rows that do not start on 16-byte boundaries, decoded rows
+// whose stride is not a multiple of 16 -- are re-laid through stream-ordered scratch INSIDE the library (round 3; the
+// Python wrapper used to copy them), so every caller of the C ABI reaches the tuned kernels.  (scl_core.hip)
+// SCL_ANY_PARAMETER_KERNELS=1 in the environment keeps the tuned kernels out altogether (tests, stress tools: it is
+// how the two implementations of every coder are compared word for word).
+bool scl_force_generic(void);
+struct RowRelay {
+    u8 *scratch = nullptr;
+    hipStream_t st = nullptr;
+    u8 *user_out = nullptr;  // decode side: where the rows go back to
+    u64 user_stride = 0, stride = 0, n_rows = 0;
+    u32 row_bytes = 0;
+    // encode side: d_sym / sym_stride are replaced by an aligned copy when they are not aligned
+    int in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks, hipStream_t stream);
+    // decode side: d_out / out_stride are replaced by aligned scratch; out_end() copies the rows back
+    int out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, hipStream_t stream);
+    int out_end();
+    ~RowRelay();
+};
+static inline bool scl_rows_aligned(const void *p, u64 stride) { return (((uintptr_t)p | stride) & 15) == 0; }
+
 // RAII-less scratch helper for the *_host convenience calls
 struct ScratchDev {
     void *p = nullptr;

@@ -1,6 +1,7 @@
 // scl_core.hip -- library plumbing: errors, device query, stream compaction / framing,
 // and the single-chunk host drivers behind the drop-in encode_block / decode_block.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -49,6 +50,89 @@ int scl_check_device(int model_device, const char *what) {
     scl_set_error("%s: the model was created on device %d but the current device is %d (one model per device: "
                   "create a handle on every GPU that uses it, or hipSetDevice before the call)", what, model_device, cur);
     return SCL_E_PARAM;
+}
+
+// ---- rows the tuned kernels cannot take as they are ----------------------------------------------------
+bool scl_force_generic(void) {
+    const char *e = getenv("SCL_ANY_PARAMETER_KERNELS");
+    return e && e[0] == '1';
+}
+
+// dst[r * dst_stride + b] = src[r * src_stride + b] for b < row_bytes: four bytes per lane, no alignment assumed
+__global__ void __launch_bounds__(256) relay_rows_kernel(u8 *__restrict__ dst, u64 dst_stride, const u8 *__restrict__ src,
+                                                        u64 src_stride, u32 row_bytes, u64 n_rows) {
+    const u32 quads = (row_bytes + 3) / 4;
+    const u64 total = n_rows * quads;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += (u64)gridDim.x * 256) {
+        const u64 r = i / quads;
+        const u32 b = (u32)(i - r * quads) * 4;
+        const u8 *s = src + r * src_stride + b;
+        u8 *d = dst + r * dst_stride + b;
+        const u32 n = min(4u, row_bytes - b);
+        for (u32 j = 0; j < n; ++j) d[j] = s[j];
+    }
+}
+
+static int relay_launch(u8 *dst, u64 dst_stride, const u8 *src, u64 src_stride, u32 row_bytes, u64 n_rows, hipStream_t st) {
+    if (!n_rows || !row_bytes) return SCL_OK;
+    const u64 total = n_rows * ((row_bytes + 3) / 4);
+    u64 blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(relay_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, dst, dst_stride, src, src_stride, row_bytes,
+                       n_rows);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+int RowRelay::in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks, hipStream_t stream) {
+    if (scl_rows_aligned(d_sym, sym_stride) || n_chunks == 0) return SCL_OK;
+    if (n_chunks == 1 && ((uintptr_t)d_sym & 15) == 0) {  // one row: its stride is free
+        sym_stride = scl_round_up((u64)chunk_len + 1, 16);
+        return SCL_OK;
+    }
+    st = stream;
+    stride = scl_round_up((u64)chunk_len, 16);
+    if (stride == 0) stride = 16;
+    hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
+    if (e != hipSuccess) {
+        scratch = nullptr;
+        scl_set_error("re-laying unaligned symbol rows: hipMallocAsync(%llu) failed: %s",
+                      (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
+        return SCL_E_ALLOC;
+    }
+    if (int rc = relay_launch(scratch, stride, d_sym, sym_stride, chunk_len, n_chunks, st)) return rc;
+    d_sym = scratch;
+    sym_stride = stride;
+    return SCL_OK;
+}
+
+int RowRelay::out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, hipStream_t stream) {
+    if (scl_rows_aligned(d_out, out_stride) || n_chunks == 0) return SCL_OK;
+    st = stream;
+    stride = scl_round_up((u64)out_cap + 1, 16);
+    hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
+    if (e != hipSuccess) {
+        scratch = nullptr;
+        scl_set_error("re-laying unaligned output rows: hipMallocAsync(%llu) failed: %s",
+                      (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
+        return SCL_E_ALLOC;
+    }
+    user_out = d_out;
+    user_stride = out_stride;
+    n_rows = n_chunks;
+    row_bytes = out_cap;
+    d_out = scratch;
+    out_stride = stride;
+    return SCL_OK;
+}
+
+int RowRelay::out_end() {
+    if (!user_out) return SCL_OK;
+    return relay_launch(user_out, user_stride, scratch, stride, row_bytes, n_rows, st);
+}
+
+RowRelay::~RowRelay() {
+    if (scratch) (void)hipFreeAsync(scratch, st);
 }
 
 // ---- stream compaction ----------------------------------------------------------------------------

@@ -234,7 +234,11 @@ extern "C" int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d
     if (n_chunks == 0) return SCL_OK;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0)
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
+    if (tuned && m->fast)
+        if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (tuned && m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0)
         range_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                                  d_out_nbits, d_status, (hipStream_t)stream);
     else if (m->dev.P <= 32)
@@ -260,7 +264,11 @@ extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d
     if (n_chunks == 0) return SCL_OK;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
+    if (tuned && m->fast && ((uintptr_t)d_in & 15) == 0)
+        if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (tuned && m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
         range_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                  out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
     else if (m->dev.P <= 32)
@@ -272,7 +280,7 @@ extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d
                            d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                            d_out_lens, d_consumed, d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return SCL_OK;
+    return relay.out_end();
 }
 
 // ---- single-chunk host drivers --------------------------------------------------------------------------

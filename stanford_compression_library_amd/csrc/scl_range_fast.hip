@@ -413,14 +413,20 @@ __device__ __forceinline__ u32 rg_div(u32 d, u32 r) {
     return (u32)(((double)d + 0.5) * x);
 }
 
-// The same quotient for totals >= 256 in binary32: then r = range // M < 2^24 converts exactly and q = d // r <= M <=
-// 2^16, so fl(fl(d) * fl(1/r)) is within q 2^-22 < 2^-6 of d / r (three roundings of 2^-24, 2^-23, 2^-24); biased down
-// by 2^-5 inside the FMA it lies in (d/r - 0.047, d/r - 0.015), i.e. its floor is q or q - 1 (0 for a negative value:
-// v_cvt_u32_f32 clamps), and one remainder test settles which: 9 instructions, none of them binary64 (the ten
-// above cost ~24 ns per wave on a SIMD, these ~16: tools/ubench/valu_rate.hip).
+// The same quotient for totals >= 256 in binary32: then r = range // M < 2^24 converts exactly and, for every state a
+// valid stream can produce, q = d // r < M <= 2^16, so fl(fl(d) * fl(1/r)) is within q 2^-22 < 2^-6 of d / r (three
+// roundings of 2^-24, 2^-23, 2^-24); biased down by 2^-5 inside the FMA it lies in (d/r - 0.047, d/r - 0.015), i.e. its
+// floor is q or q - 1, and one remainder test settles which: 9 instructions, none of them binary64 (the ten above cost
+// ~24 ns per wave on a SIMD, these ~16: tools/ubench/valu_rate.hip).
+// The conversion is the hardware's (v_cvt_u32_f32: negative -> 0, >= 2^32 -> 0xFFFFFFFF), written as an instruction
+// because the C++ cast is undefined outside [0, 2^32) -- a negative value occurs for d = 0 (valid), a huge one only for
+// CORRUPT input (the normalisation keeps range >= BOTTOM >= M, so r >= 1, and d / r >= 2^32 needs r = 1 and
+// d >= 2^32 - 2^7): there q saturates, q + 1 wraps to 0 and this path decodes slot 0 where rg_div and the generic
+// kernel decode the last slot -- both outputs are garbage the range coder has no means to detect.
 __device__ __forceinline__ u32 rg_div32(u32 d, u32 r) {
     const float qf = __builtin_fmaf((float)d, __builtin_amdgcn_rcpf((float)r), -0.03125f);
-    u32 q = (u32)qf;                      // q or q - 1
+    u32 q;  // q or q - 1
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(qf));
     const u32 rem = d - __umul24(q, r);   // q < 2^17, r < 2^24; rem in [0, 2r)
     return q + (rem >= r ? 1u : 0u);
 }

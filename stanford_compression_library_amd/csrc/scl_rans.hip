@@ -270,12 +270,16 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
     hipStream_t st = (hipStream_t)stream;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
+    if (tuned && (m->fast || m->fastb) && out_stride >= scl_rans_slot_bytes(m, chunk_len))
+        if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, st)) return rc_r;
     // fast path: qualifying model, 16-byte aligned rows, and slots that cannot overflow (it has no capacity check)
-    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+    if (tuned && m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
         out_stride >= scl_rans_slot_bytes(m, chunk_len) && out_stride < (1ull << 24))  // 256 slots within 32-bit offsets
         rans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                 d_out_bit_offset, d_out_nbits, d_status, st);
-    else if (m->fastb && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+    else if (tuned && m->fastb && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
              out_stride >= scl_rans_slot_bytes(m, chunk_len))
         rans_fastb_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                  d_out_bit_offset, d_out_nbits, d_status, st);
@@ -301,10 +305,14 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
     hipStream_t st = (hipStream_t)stream;
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
-    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
+    if (tuned && (m->fast || m->fastb) && ((uintptr_t)d_in & 15) == 0)
+        if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, st)) return rc_r;
+    if (tuned && m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
         rans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, st);
-    else if (m->fastb && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
+    else if (tuned && m->fastb && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0)
         rans_fastb_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                  out_cap, d_out_lens, d_consumed, d_status, st);
     else if (m->state32)
@@ -316,7 +324,7 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
                            d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return SCL_OK;
+    return relay.out_end();
 }
 
 // ---- single-chunk host drivers ------------------------------------------------------------------------

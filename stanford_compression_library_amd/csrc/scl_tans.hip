@@ -344,14 +344,18 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
                 "tans_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "tans_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
-    if (m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
+    if ((tuned || !m->tables) && (m->fast || m->rans))
+        if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (tuned && m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
         out_stride >= scl_tans_slot_bytes(m, chunk_len)) {
         tans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                                 d_out_nbits, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
-    if (m->rans && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
+    if ((tuned || !m->tables) && m->rans && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
         out_stride >= scl_rans_slot_bytes(m->rans, chunk_len) &&
         out_stride < (1ull << 24)) {  // same stream from the table-free rANS kernels (32-bit slot offsets per workgroup)
         rans_fast_encode_launch(m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
@@ -381,17 +385,22 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
     if (int rc_dev = scl_check_device(m->device, "tans_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "tans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
-    if (m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
+    const bool tuned = !scl_force_generic();
+    RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
+    if ((tuned || !m->tables) && (m->fast || m->rans) && ((uintptr_t)d_in & 15) == 0)
+        if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (tuned && m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
         tans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
-        return SCL_OK;
+        return relay.out_end();
     }
-    if (m->rans && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
+    if ((tuned || !m->tables) && m->rans && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
+        (out_stride & 15) == 0) {
         rans_fast_decode_launch(m->rans, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
-        return SCL_OK;
+        return relay.out_end();
     }
     SCL_REQUIRE(m->tables, "tans_decode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned buffers");
@@ -403,7 +412,7 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                        in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                        d_consumed, d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return SCL_OK;
+    return relay.out_end();
 }
 
 // ---- single-chunk host drivers --------------------------------------------------------------------------

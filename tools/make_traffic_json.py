@@ -1,25 +1,61 @@
-"""pmc_summary.txt -> traffic.json: HBM bytes per launch for the rANS encode / decode kernels.
-FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes
-(MI355X_MICROARCH.md, HBM section: "reports exactly 1/2 of the bytes of a wide coalesced streaming read"), so it is
-doubled for both kernels, whose lanes read whole 128-byte lines (calibration on the encode kernel: 2 x FETCH_SIZE
-= 1.01 x the 1 GiB it must read; while the decode kernel still read 64-byte blocks, r01_v4, its FETCH_SIZE equalled
-the stream bytes at face value and halved when it switched to whole lines).  WRITE_SIZE is taken as is."""
+"""pmc_summary.txt + the bench.py line of the same run -> one traffic entry: HBM bytes per launch of the encode and the
+decode kernel of that workload (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean per dispatch).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte read request at 64 bytes
+(MI355X_MICROARCH.md, HBM section: "reports exactly 1/2 of the bytes of a wide coalesced streaming read ... other access
+widths are uncalibrated: calibrate on a known byte count in your own access pattern").  Calibration used here, per kernel:
+the bytes the kernel MUST read are known (encode: the symbols; decode: the streams); if the counter at face value is below
+0.75 x that minimum, the kernel's reads are of the wide kind and the counter is doubled, else it is taken as is.  Both the
+raw value and the multiplier are recorded.  WRITE_SIZE is taken as is (it matched the stream bytes within 1-2 % on every
+kernel of this library that was checked by construction).
+
+usage: make_traffic_json.py pmc_summary.txt bench.json out_entry.json     (one entry)
+       make_traffic_json.py --merge profiles/traffic.json entry.json ...  (replace entries with the same key)"""
 import json, re, sys
-vals = {}
-for line in open(sys.argv[1]):
-    m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch=([0-9.e+]+)", line)
-    if m:
-        kern = "rans_encode" if "encode" in m.group(1) else "rans_decode" if "decode" in m.group(1) else None
-        if kern:
-            vals.setdefault(kern, {})[m.group(2)] = float(m.group(3))
-out = {}
-for k, v in vals.items():
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        mult = 2  # both kernels read whole 128-byte lines since r01_v6
-        out[k] = int(v["FETCH_SIZE"] * 1024 * mult + v["WRITE_SIZE"] * 1024)
-        out[k + "_detail"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"], "fetch_multiplier": mult,
-                              "read_bytes": int(v["FETCH_SIZE"] * 1024 * mult), "write_bytes": int(v["WRITE_SIZE"] * 1024)}
-out["workload"] = {"coder": "rans", "table": "t256", "chunks": 262144, "chunk_len": 4096}
-out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch, 1 GiB T256 batch"
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(json.dumps(out))
+
+
+def entry(pmc_path, bench_path, out_path):
+    b = json.loads([ln for ln in open(bench_path) if ln.startswith("{")][0])
+    vals = {}
+    for line in open(pmc_path):
+        m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch=([0-9.e+]+)", line)
+        if m and "cp_" not in m.group(1):
+            side = "encode" if "encode" in m.group(1) else "decode" if "decode" in m.group(1) else None
+            if side:
+                vals.setdefault(side, {"kernel": m.group(1).strip()})[m.group(2)] = float(m.group(3))
+    in_bytes = b["config"]["chunks_per_gpu"] * b["config"]["chunk_len"]
+    stream_bytes = b["roofline_encode"]["algorithmic_bytes_per_launch"] - in_bytes
+    out = {"key": b["traffic_key"], "algorithmic_bytes_per_launch": b["roofline_encode"]["algorithmic_bytes_per_launch"]}
+    for side, v in vals.items():
+        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        must_read = in_bytes if side == "encode" else stream_bytes
+        raw = v["FETCH_SIZE"] * 1024
+        mult = 2 if raw < 0.75 * must_read else 1
+        out[side] = int(raw * mult + v["WRITE_SIZE"] * 1024)
+        out[side + "_detail"] = {"kernel": v["kernel"], "FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
+                                 "fetch_multiplier": mult, "bytes_the_kernel_must_read": int(must_read),
+                                 "read_bytes": int(raw * mult), "write_bytes": int(v["WRITE_SIZE"] * 1024)}
+    out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch"
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out))
+
+
+def merge(target, entries):
+    try:
+        cur = json.load(open(target))
+    except Exception:
+        cur = {}
+    lst = cur.get("entries", [])
+    for p in entries:
+        e = json.load(open(p))
+        lst = [x for x in lst if x.get("key") != e["key"]] + [e]
+    json.dump({"entries": lst, "note": "one entry per bench.py workload (key = bench.py's traffic_key); see tools/make_traffic_json.py"},
+              open(target, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--merge":
+        merge(sys.argv[2], sys.argv[3:])
+    else:
+        entry(*sys.argv[1:4])
