@@ -4,8 +4,11 @@
 // tANSDecoder.decode_symbol :239-250), served when RANGE_FACTOR*M <= 8192 so that the tables sit in LDS next to
 // the per-lane stream rings.  One workgroup of 1024 lanes per CU; stream I/O is the line-granular scheme of
 // scl_ans_fast_io.h (shared with the rANS fast kernels: the stream layout is identical).
-//   encode, per symbol: one 16-byte read {thresh, row offset, nbits_base+1} by symbol, then one 2-byte read of
-//                       base_encode_step_table[(s, x >> nb)] by state -- no multiply, no divide;
+//   encode, per symbol: one 8-byte read {thresh | (nbits_base+1) << 16, row address} by symbol, then one 2-byte read
+//                       of base_encode_step_table[(s, x >> nb)] by state -- no multiply, no divide.  (16-byte entries
+//                       until round 3: the encoder was LDS bound, 82 % busy with random 16-byte gathers at half the
+//                       LDS rate, profiles/r03_instruction_mix.txt; thresh <= 2L <= 2^14 and nbits <= 14 share a word
+//                       at no cost, the two subtractions that use them select their half by SDWA);
 //   decode, per symbol: one 4-byte read base_decode_step_table[x] = (x_shrunk << 8 | s) by state;
 //                       expand_state_num_bits_table is clz.
 #include <vector>
@@ -23,12 +26,9 @@ struct TfSym {
 };
 
 __device__ __forceinline__ TfSym tf_encode_symbol(u32 &x, u32 addr, const char *sym_tab, const char *lds) {
-    const uint4 e = *reinterpret_cast<const uint4 *>(sym_tab + addr);
-    // keep the read a ds_read_b128: shrunk to the 12 bytes in use it becomes a ds_read_b96, which is far slower on this
-    // chip (rANS encoder: 0.58 -> 0.68 ms with b96 table reads)
-    asm volatile("" : : "v"(e.w));
-    const u32 neg = (x - e.x) >> 31;  // 1 iff x < shrink_state_thresh_table[s]
-    const u32 nb = e.z - neg;         // shrink_state_num_out_bits_base_table[s] (+1 above the threshold)
+    const uint2 e = *reinterpret_cast<const uint2 *>(sym_tab + addr);
+    const u32 neg = (x - (e.x & 0xFFFFu)) >> 31;  // 1 iff x < shrink_state_thresh_table[s]
+    const u32 nb = (e.x >> 16) - neg;             // shrink_state_num_out_bits_base_table[s] (+1 above the threshold)
     TfSym r;
     r.bits = __builtin_amdgcn_ubfe(x, 0, nb);
     r.k = nb;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void tf_encode16(const uint4 v, u32 &x, TfOut &o, u32
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const u32 w = wv[d];
-        const u32 a0 = (w << 4) & 0xFF0u, a1 = (w >> 4) & 0xFF0u, a2 = (w >> 12) & 0xFF0u, a3 = (w >> 20) & 0xFF0u;
+        const u32 a0 = (w << 3) & 0x7F8u, a1 = (w >> 5) & 0x7F8u, a2 = (w >> 13) & 0x7F8u, a3 = (w >> 21) & 0x7F8u;
         bad = max(max(bad, max(a0, a1)), max(a2, a3));
         const TfSym s0 = tf_encode_symbol(x, a0, sym_tab, lds);
         const TfSym s1 = tf_encode_symbol(x, a1, sym_tab, lds);
@@ -70,9 +70,9 @@ __global__ void __launch_bounds__(THREADS) tans_encode_fast_kernel(TansFastDev P
     char *lds = s_lds;
     const char *sym_tab = s_lds + TF_RING_BYTES;
     if (threadIdx.x < 256) {  // row offsets are stored relative to the step table: make them LDS addresses
-        uint4 e = P.d_enc_sym[threadIdx.x];
-        e.y += TF_RING_BYTES + 4096;
-        reinterpret_cast<uint4 *>(s_lds + TF_RING_BYTES)[threadIdx.x] = e;
+        const uint4 e = P.d_enc_sym[threadIdx.x];
+        reinterpret_cast<uint2 *>(s_lds + TF_RING_BYTES)[threadIdx.x] =
+            make_uint2(e.x | (e.z << 16), e.y + TF_RING_BYTES + 4096);
     }
     for (u32 i = threadIdx.x; i < P.L; i += THREADS)
         reinterpret_cast<u16 *>(s_lds + TF_RING_BYTES + 4096)[i] = P.d_enc_tab[i];
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(THREADS) tans_encode_fast_kernel(TansFastDev P
         o.maybe_flush(lds);
     }
     for (; i < n; ++i) {
-        const u32 a = (u32)src[i] << 4;
+        const u32 a = (u32)src[i] << 3;
         bad = max(bad, a);
         const TfSym s = tf_encode_symbol(x, a, sym_tab, lds);
         o.put(lds, s.bits, s.k);
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(THREADS) tans_encode_fast_kernel(TansFastDev P
     }
     o.maybe_flush(lds);
     o.put32(lds, x, P.nsb);
-    u32 st = (bad >= (P.K << 4)) ? SCL_ST_SYMBOL : 0u;
+    u32 st = (bad >= (P.K << 3)) ? SCL_ST_SYMBOL : 0u;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
     o.put32(lds, n, P.size_bits);
     const u64 total = o.finish(lds);
