@@ -521,7 +521,8 @@ extern "C" uint64_t scl_aec_scratch_bytes(const scl_aec_model *m, uint64_t n_chu
 }
 
 extern "C" int scl_aec_fast_path(const scl_aec_model *m, uint64_t max_symbols) {
-    return (m && (aec_fast_ok(m, max_symbols) || aec_static_ok(m) || aec_iid_ok(m, max_symbols))) ? 1 : 0;
+    return (m && (aec_fast_ok(m, max_symbols) || aec_static_ok(m) || aec_iid_ok(m, max_symbols) ||
+                  aec_wide_ok(m, max_symbols))) ? 1 : 0;
 }
 
 // per-lane context tables in LDS: at most 256 cells, counts (initial + one per symbol) must fit 16 bits
@@ -554,7 +555,7 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     hipStream_t st = (hipStream_t)stream;
     const bool tuned = !scl_force_generic();
     RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
-    if (tuned && (aec_fast_ok(m, chunk_len) || aec_iid_ok(m, chunk_len) || aec_static_ok(m)) &&
+    if (tuned && (aec_fast_ok(m, chunk_len) || aec_iid_ok(m, chunk_len) || aec_static_ok(m) || aec_wide_ok(m, chunk_len)) &&
         out_stride >= scl_aec_slot_bytes(m, chunk_len))
         if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, st)) return rc_r;
     // small-alphabet adaptive models: cumulative context rows in LDS, closed-form renormalisation (scl_aec_fast.hip)
@@ -586,6 +587,14 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
         if (rc) return rc;
     }
+    // order-k on a large alphabet: the same device-memory rows, tuned arithmetic, lookups issued ahead (scl_aec_wide.hip)
+    if (tuned && aec_wide_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
+        sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
+        aec_wide_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                               d_out_nbits, d_status, (u32 *)d_scratch, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
+    }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     if (aec_use_lds(m, chunk_len))
@@ -613,7 +622,8 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     hipStream_t st = (hipStream_t)stream;
     const bool tuned = !scl_force_generic();
     RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
-    if (tuned && (aec_fast_ok(m, out_cap) || aec_iid_ok(m, out_cap) || aec_static_ok(m)) && ((uintptr_t)d_in & 15) == 0)
+    if (tuned && (aec_fast_ok(m, out_cap) || aec_iid_ok(m, out_cap) || aec_static_ok(m) || aec_wide_ok(m, out_cap)) &&
+        ((uintptr_t)d_in & 15) == 0)
         if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, st)) return rc_r;
     if (tuned && aec_fast_ok(m, out_cap) && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
         (out_stride & 15) == 0 && out_stride >= scl_round_up(out_cap, 16)) {
@@ -639,6 +649,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     if (!aec_use_lds(m, out_cap)) {
         int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
         if (rc) return rc;
+    }
+    if (tuned && aec_wide_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
+        out_stride >= scl_round_up(out_cap, 4)) {
+        aec_wide_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                               d_out_lens, d_consumed, d_status, (u32 *)d_scratch, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return relay.out_end();
     }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
