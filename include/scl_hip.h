@@ -179,7 +179,9 @@ typedef struct scl_aec_model scl_aec_model;
    object); coder objects that live across blocks (quirk Q4) use the *_resume entry points below.
    h_freq_init: initial frequencies [K] for FIXED / IID (ignored for ORDERK, which starts from
    all-ones counts).  order_k: context length for ORDERK (0..3).  max_total: the model's
-   max_allowed_total_freq.  precision 8..32. */
+   max_allowed_total_freq.  precision 8..62: up to 32 the tuned kernels serve the models listed at
+   scl_aec_fast_path; 33..62 run the any-parameter kernels with low / high in 128 bits (row totals must stay
+   below 2^32: SCL_ST_TOTAL otherwise). */
 int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init, uint32_t K, uint32_t order_k,
                          uint64_t max_total, uint32_t precision, uint32_t size_bits,
                          scl_aec_model **out);

@@ -306,6 +306,23 @@ def gen_aec(col, rng):
     add_coder_case(col, "aec", dict(group="G7halve", model="iid", freq=[1] * 4, K=4, k=0, max_total=p.MAX_ALLOWED_TOTAL_FREQ,
                                     precision=16, size_bits=32), alphabet, syms,
                    lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
+    # G7wide: PRECISION above 32.  The reference's dataclass takes any value, its arithmetic does not: low / high are
+    # Python integers but the cumulative counts are numpy int64, so range * count silently wraps once PRECISION +
+    # bit_length(total) exceeds 63, and PRECISION = 64 dies with a TypeError in `low << 1` (probed here; like quirk Q7).
+    # 40 and 48 with small totals are inside its sound region.
+    for prec in (40, 48):
+        fl = [12, 34, 1, 45]
+        alphabet = list("ABCD")
+        p = AECParams(PRECISION=prec)
+        syms = iid_indices(fl, 600, seed=prec)
+        fr_init = Frequencies(dict(zip(alphabet, fl)))
+        for model_name, mk, freq, k in (
+                ("fixed", lambda: FixedFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ), fl, 0),
+                ("iid", lambda: AdaptiveIIDFreqModel(fr_init, p.MAX_ALLOWED_TOTAL_FREQ), fl, 0),
+                ("orderk", lambda: AdaptiveOrderKFreqModel(alphabet, 1, p.MAX_ALLOWED_TOTAL_FREQ), [1] * 4, 1)):
+            add_coder_case(col, "aec", dict(group="G7wide", model=model_name, freq=freq, K=4, k=k,
+                                            max_total=p.MAX_ALLOWED_TOTAL_FREQ, precision=prec, size_bits=32),
+                           alphabet, syms, lambda: ArithmeticEncoder(p, mk()), lambda: ArithmeticDecoder(p, mk()), rng)
     # short blocks incl. length 1 (length 0 never terminates in the reference decoder, quirk Q5)
     for n in (1, 2, 3, 9):
         fl = [2, 1, 5]

@@ -48,8 +48,11 @@ class _AecBase:
         if self._model is None:
             spec = self.freq_model.device_spec()
             check_alphabet(spec["alphabet"])
-            if not 8 <= self.params.PRECISION <= 32:
-                raise NotImplementedError("PRECISION outside 8..32: the gfx950 kernels keep low/high in 33 bits")
+            if not 8 <= self.params.PRECISION <= 62:
+                # 33..62 run the any-parameter kernels with low / high in 128 bits.  The reference's dataclass takes any
+                # value but its arithmetic does not: PRECISION = 64 dies with a TypeError in `low << 1`, and range * count
+                # wraps in numpy int64 once PRECISION + bit_length(total) exceeds 63 (oracle/gen_goldens.py, G7wide)
+                raise NotImplementedError("PRECISION outside 8..62")
             self._model = AecModel(spec["kind"], spec["freq_init"], spec["K"], spec["k"], spec["max_total"],
                                    self.params.PRECISION, self.params.DATA_BLOCK_SIZE_BITS)
             self._alphabet = list(spec["alphabet"])

@@ -229,7 +229,48 @@ struct LaneModel {
     }
 };
 
-template <bool LDS16>
+// ---- PRECISION above 32 (round 3) ---------------------------------------------------------------------------
+// low / high reach 2^PRECISION and range * count 2^(2 PRECISION - 2): the any-parameter kernels run them in 128 bits
+// (WIDE = true) for PRECISION 33..62; the reference uses Python integers for low / high (but numpy int64 for the
+// counts: its own products wrap once PRECISION + bit_length(total) exceeds 63 -- there these kernels compute the exact
+// value, the reference does not).  Totals are below 2^32 here (the cells are u32), which the division relies on.
+typedef unsigned __int128 u128;
+template <bool WIDE>
+struct AecWord {
+    typedef u64 T;
+};
+template <>
+struct AecWord<true> {
+    typedef u128 T;
+};
+// floor(rng * c / T)
+__device__ __forceinline__ u64 aec_muldiv(u64 rng, u64 c, u64 T) { return (rng * c) / T; }
+__device__ __forceinline__ u128 aec_muldiv(u128 rng, u64 c, u64 T) {  // T < 2^32: four base-2^32 digits
+    const u128 n = rng * c;
+    u64 rem = 0;
+    u128 q = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        const u64 cur = (rem << 32) | (u64)((u32)(n >> (32 * d)));
+        const u64 qd = cur / T;
+        rem = cur - qd * T;
+        q = (q << 32) | qd;
+    }
+    return q;
+}
+// floor(((state - low + 1) * T - 1) / rng): the decoder's search bound (see the file header); the quotient is < T
+__device__ __forceinline__ u64 aec_cmax(u64 state, u64 low, u64 T, u64 rng) { return ((state - low + 1) * T - 1) / rng; }
+__device__ __forceinline__ u64 aec_cmax(u128 state, u128 low, u64 T, u128 rng) {
+    const u128 num = (state - low + 1) * T - 1;  // < 2^62 * 2^32
+    const double nd = (double)(u64)(num >> 64) * 18446744073709551616.0 + (double)(u64)num;
+    const double rd = (double)(u64)(rng >> 64) * 18446744073709551616.0 + (double)(u64)rng;
+    u64 q = (u64)(nd / rd);  // within a few units of the quotient (< 2^32, relative error 2^-50)
+    while ((u128)q * rng > num) --q;
+    while ((u128)(q + 1) * rng <= num) ++q;
+    return q;
+}
+
+template <bool LDS16, bool WIDE = false>
 __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__restrict__ sym, u64 sym_stride,
                                                         const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                         u8 *__restrict__ out, u64 out_stride,
@@ -248,7 +289,8 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
+    typedef typename AecWord<WIDE>::T W;
+    const W FULL = (W)1 << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
     LaneModel<LDS16> mdl;
     mdl.init(&P, scratch, c, s_cnt + threadIdx.x, ctx_state);
     FwdBitWriter w;
@@ -256,7 +298,8 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     u32 st = 0;
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
     w.put(n, P.size_bits);
-    u64 low = 0, high = FULL, pending = 0;
+    W low = 0, high = FULL;
+    u64 pending = 0;
     for (u32 i = 0; i < n; ++i) {
         u32 s = src[i];
         if (s >= P.K) {
@@ -265,13 +308,13 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
         }
         u64 cs, fs, T;
         mdl.lookup(s, s_f, s_c, cs, fs, T);
-        if (T >= QTR) {  // assert total_freq < MAX_ALLOWED_TOTAL_FREQ, arithmetic_coding.py:110-112
+        if (T >= QTR || (WIDE && (T >> 32))) {  // assert total_freq < MAX_ALLOWED_TOTAL_FREQ, arithmetic_coding.py:110-112
             st |= SCL_ST_TOTAL;
             break;
         }
-        const u64 rng = high - low;  // shrink_range :70-77
-        high = low + (rng * (cs + fs)) / T;
-        low = low + (rng * cs) / T;
+        const W rng = high - low;  // shrink_range :70-77
+        high = low + aec_muldiv(rng, cs + fs, T);
+        low = low + aec_muldiv(rng, cs, T);
         mdl.update(s, fs);  // :118
         while (high < HALF || low > HALF) {  // E1 / E2, :126-143
             if (high < HALF) {
@@ -310,7 +353,7 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     if (status) status[c] = st;
 }
 
-template <bool LDS16>
+template <bool LDS16, bool WIDE = false>
 __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                                                         const u64 *__restrict__ bit_off,
                                                         const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -328,7 +371,8 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
     __syncthreads();
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    const u64 FULL = 1ull << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
+    typedef typename AecWord<WIDE>::T W;
+    const W FULL = (W)1 << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
     BitReader r;
     r.init(in, in_size_bytes, bit_off[c], in_nbits[c]);
     u32 st = 0;
@@ -353,21 +397,21 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
     // bit positions relative to the first bit after the header; bits past the end read as 0 (:258-261)
     const u64 body = r.pos;
     u64 used = P.P;  // the state register is always filled with PRECISION bits (:222-229)
-    u64 state = r.peek_at(body, P.P);
-    u64 low = 0, high = FULL;
+    W state = P.P > 32 ? ((W)r.peek_at(body, P.P - 32) << 32) | r.peek_at(body + P.P - 32, 32) : (W)r.peek_at(body, P.P);
+    W low = 0, high = FULL;
     u32 ndec = 0;
     for (;;) {
         const u64 T = mdl.total(s_f);
-        if (T >= QTR) {
+        if (T >= QTR || (WIDE && (T >> 32))) {
             st |= SCL_ST_TOTAL;
             break;
         }
-        const u64 rng = high - low;
-        const u64 cmax = ((state - low + 1) * T - 1) / rng;  // see file header
+        const W rng = high - low;
+        const u64 cmax = aec_cmax(state, low, T, rng);  // see file header
         u64 cs, fs;
         const u32 s = mdl.search(cmax, s_f, s_c, cs, fs);
-        high = low + (rng * (cs + fs)) / T;
-        low = low + (rng * cs) / T;
+        high = low + aec_muldiv(rng, cs + fs, T);
+        low = low + aec_muldiv(rng, cs, T);
         dst[ndec++] = (u8)s;
         mdl.update(s, fs);
         if (ndec == n) break;  // before the renormalisation, :242-243
@@ -395,7 +439,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     u32 e = 0;
     for (; e < P.P; ++e) {
-        const u64 slo = (state >> e) << e, shi = slo + (1ull << e);
+        const W slo = (state >> e) << e, shi = slo + ((W)1 << e);
         if (slo < low || shi > high) break;
     }
     if (e == P.P) e = P.P - 1;  // Python's loop variable after an unbroken range(PRECISION)
@@ -413,7 +457,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     SCL_REQUIRE(model_kind == SCL_MODEL_FIXED || model_kind == SCL_MODEL_IID || model_kind == SCL_MODEL_ORDERK,
                 "aec_model_create: unknown model kind %d", model_kind);
     SCL_REQUIRE(K >= 1 && K <= 256, "aec_model_create: alphabet size %u outside 1..256", K);
-    SCL_REQUIRE(precision >= 8 && precision <= 32, "aec_model_create: PRECISION %u outside 8..32", precision);
+    SCL_REQUIRE(precision >= 8 && precision <= 62, "aec_model_create: PRECISION %u outside 8..62", precision);
     SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "aec_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32", size_bits);
     SCL_REQUIRE(max_total >= 2, "aec_model_create: max_allowed_total_freq too small");
     scl_aec_model *m = new scl_aec_model();
@@ -598,13 +642,27 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     if (aec_use_lds(m, chunk_len))
-        hipLaunchKernelGGL(aec_encode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+        do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_encode_kernel<true, true>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
                            (u32 *)d_scratch, (u64 *)nullptr);
+        else
+            hipLaunchKernelGGL((aec_encode_kernel<true, false>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
+                           (u32 *)d_scratch, (u64 *)nullptr);
+    } while (0);
     else
-        hipLaunchKernelGGL(aec_encode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+        do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_encode_kernel<false, true>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
                            d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
                            (u32 *)d_scratch, (u64 *)nullptr);
+        else
+            hipLaunchKernelGGL((aec_encode_kernel<false, false>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status,
+                           (u32 *)d_scratch, (u64 *)nullptr);
+    } while (0);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -660,13 +718,27 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     if (aec_use_lds(m, out_cap))
-        hipLaunchKernelGGL(aec_decode_kernel<true>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+        do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_decode_kernel<true, true>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                            d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
+        else
+            hipLaunchKernelGGL((aec_decode_kernel<true, false>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
+    } while (0);
     else
-        hipLaunchKernelGGL(aec_decode_kernel<false>, dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+        do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_decode_kernel<false, true>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                            d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
+        else
+            hipLaunchKernelGGL((aec_decode_kernel<false, false>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                           d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
+    } while (0);
     SCL_HIP_TRY(hipGetLastError());
     return relay.out_end();
 }
@@ -824,9 +896,16 @@ extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t
                 (unsigned long long)scl_aec_state_bytes(m, n_coders));
     if (n_chunks == 0) return SCL_OK;
     u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
-    hipLaunchKernelGGL(aec_encode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_encode_kernel<false, true>), dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        m->dev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                        d_out_nbits, d_status, (u32 *)d_state, ctx_state);
+        else
+            hipLaunchKernelGGL((aec_encode_kernel<false, false>), dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       m->dev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                       d_out_nbits, d_status, (u32 *)d_state, ctx_state);
+    } while (0);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -853,9 +932,16 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
                 (unsigned long long)scl_aec_state_bytes(m, n_coders));
     if (n_chunks == 0) return SCL_OK;
     u64 *ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
-    hipLaunchKernelGGL(aec_decode_kernel<false>, dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    do {
+        if (m->dev.P > 32)
+            hipLaunchKernelGGL((aec_decode_kernel<false, true>), dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        m->dev, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                        d_out_lens, d_consumed, d_status, (u32 *)d_state, ctx_state);
+        else
+            hipLaunchKernelGGL((aec_decode_kernel<false, false>), dim3((u32)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       m->dev, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                       d_out_lens, d_consumed, d_status, (u32 *)d_state, ctx_state);
+    } while (0);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }

@@ -702,6 +702,52 @@ def test_random_arithmetic_models_vs_oracle(seed, dev):
             assert used[c] == o_dec(rb, rn)[1], f"{kind} K={K} chunk {c}"
 
 
+@pytest.mark.parametrize("precision", [33, 40, 48, 56, 62])
+@pytest.mark.parametrize("kind", ["fixed", "iid", "orderk"])
+def test_arithmetic_wide_precision_vs_oracle(precision, kind, dev):
+    """PRECISION above 32 (round 3): the any-parameter kernels with low / high in 128 bits against the oracle (pinned on
+    the reference's PRECISION 40 / 48 goldens, G7wide); ragged chunks, streams and consumed-bit counts; totals up to
+    2^31 for the static model (the products then need all 128 bits)."""
+    rng = np.random.default_rng(precision * 7 + len(kind))
+    cap = 300
+    lens = np.concatenate([[0, 1, 2, 299, 300], rng.integers(0, cap + 1, 11)]).astype(np.int32)
+    max_total = 1 << (precision - 2)
+    if kind == "fixed":
+        K = 37
+        f = rng.integers(1, 1 << 26, K).astype(np.uint32)  # total ~2^30
+        model = models.AecModel(0, f.tolist(), K, 0, max_total, precision, 32)
+        kw = dict(model_kind=orc.MODEL_FIXED, K=K, f_init=f)
+        p = f / f.sum()
+    elif kind == "iid":
+        K = 20
+        f = rng.integers(1, 60, K).astype(np.uint32)
+        model = models.AecModel(1, f.tolist(), K, 0, max_total, precision, 32)
+        kw = dict(model_kind=orc.MODEL_IID, K=K, f_init=f)
+        p = rng.dirichlet(np.full(K, 0.3))
+    else:
+        K, k = 5, 2
+        model = models.AecModel(2, None, K, k, max_total, precision, 32)
+        kw = dict(model_kind=orc.MODEL_ORDERK, K=K, k=k)
+        p = rng.dirichlet(np.full(K, 0.5))
+    kw.update(max_total=max_total, precision=precision, size_bits=32)
+    assert not model.fast_path(cap)
+    sym = rng.choice(K, (lens.size, cap), p=p).astype(np.uint8)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    for c in range(lens.size):
+        rb, rn = orc.aec_encode(sym[c, :lens[c]], **kw)
+        assert int(nbits[c]) == rn, (kind, precision, c)
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), (kind, precision, c)
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), (kind, precision, c)
+        if lens[c] > 0:
+            assert used[c] == orc.aec_decode(rb, rn, **kw)[1], (kind, precision, c)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 16))))
 def test_random_totals_fast_paths_vs_oracle(seed, dev):
     """rANS with ANY total 2..4096 (the reference does not ask for a power of two, and its own tests use 5, 30, 92,
