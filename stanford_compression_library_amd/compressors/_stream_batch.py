@@ -99,6 +99,7 @@ class BatchedStreamDecoderMixin:
         from ..core.data_block import DataBlock
         from ..utils.bitarray_utils import BitArray
 
+        self._batch_model()  # creates the device model and, with it, self._size_bits
         # walk the 4-byte block headers on the host (one per block); the payload bits stay where they are
         sb = self._size_bits
         offs, nbits, sizes, pos = [], [], [], 0
