@@ -29,9 +29,11 @@ if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "r
              "fixed_k64": lambda: models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
              "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
              "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
-else:
-    base = np.stack([bench_data.markov1_host(16, chunk_len, seed=900 + c) for c in range(512)])
-    sym = torch.from_numpy(base).to(dev).repeat(n_chunks // 512, 1).contiguous()
+elif mode == "order1_k256":  # scl_aec_wide.hip (device-memory rows): NCHUNKS=65536 keeps the tables at 17.8 GB
+    sym = bench_data.markov1_chunks_device(256, n_chunks, chunk_len, seed=901, device=dev)
+    model = models.AecModel(2, None, 256, 1, 1 << 30, 32, 32)
+else:  # order-1, K = 16: scl_aec_split.hip (encode) / scl_aec_fast.hip (decode); every chunk distinct
+    sym = bench_data.markov1_chunks_device(16, n_chunks, chunk_len, seed=900, device=dev)
     model = models.AecModel(2, None, 16, 1, 1 << 30, 32, 32)
 if isinstance(model, models.AecModel):
     assert model.fast_path(chunk_len)
