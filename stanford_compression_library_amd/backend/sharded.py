@@ -309,8 +309,10 @@ def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: Optional[
     dev = sym.device
     n_chunks, chunk_len = sym.shape
     n_sub = default_sub_batches(n_chunks) if n_sub is None else int(n_sub)
-    if n_chunks and (sym.stride(0) % 16 or sym.data_ptr() % 16):
-        sym = torch.nn.functional.pad(sym, (0, -chunk_len % 16))[:, :chunk_len]  # rows on 16-byte boundaries
+    if n_chunks and (sym.stride(0) % 16 or sym.data_ptr() % 16):  # rows on 16-byte boundaries (encode_rows_into)
+        padded = torch.empty((n_chunks, (chunk_len + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+        padded[:, :chunk_len] = sym
+        sym = padded[:, :chunk_len]
     ws = workspace
     if ws is None or not ws.matches(model, sym, world, n_sub, framed):
         ws = GatherWorkspace(model, n_chunks, chunk_len, world, dev, n_sub, framed)
