@@ -133,9 +133,9 @@ __global__ void __launch_bounds__(AI_THREADS)
         T += 1;
     };
     auto code = [&](u32 cc, u32 dd, u32 TT, double xx) {
-        af_shrink(low, hm, cc, dd, TT, xx);
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        af_shrink2(low, hm, cc, dd, xx);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge || (k + pending > 32), 0)) {
             u64 lo = low, hi = (u64)hm + 1;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -169,9 +169,8 @@ __global__ void __launch_bounds__(AI_THREADS)
                 pending = 0;
             }
             pending += m;
-            const u32 kt = k + m;  // <= 31
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
         }
     };
 
@@ -284,7 +283,7 @@ __global__ void __launch_bounds__(AI_THREADS)
         XB = ai_row_add(XB, gt_a, gt_b);
         *reinterpret_cast<uint4_lds *>(lds + tid * 32) = XB.a;
         *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
-        af_shrink(low, hm, c, d, T, xT);
+        af_shrink2(low, hm, c, d, xT);
         T += 1;
         // ---- symbol out ----
         oword |= s << (8 * (i & 3));
@@ -294,8 +293,8 @@ __global__ void __launch_bounds__(AI_THREADS)
         }
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -326,8 +325,8 @@ __global__ void __launch_bounds__(AI_THREADS)
             const u32 bits = rd.get(kt);
             const u32 keep = (state << k) & AF_HALF;
             state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
             used += kt;
         }
     }

@@ -39,3 +39,29 @@ __device__ __forceinline__ bool af_renorm_counts(u32 low, u32 hm, u32 &k, u32 &m
     return max(e_lo, e_hi) >= 32;
 }
 
+
+// ---- round-3 forms (scl_aec_split.hip first, then every tuned arithmetic-coder kernel) ------------------------------
+// shrink_range without the d == T special case: high' - 1 = low + ((rng d) // T - 1) with the "- 1" inside the FMA, so
+// the value converted is at most 2^32 - 1 even when the quotient is 2^32 (rng = 2^32, d = T).  (rng d) // T >= 1 always
+// (rng > 2^30 after a renormalisation, d >= 1, T <= 2^16), so trunc(v - 1) = trunc(v) - 1; precision as in af_shrink.
+__device__ __forceinline__ void af_shrink2(u32 &low, u32 &hm, u32 c, u32 d, double x) {
+    const double rd = (double)(hm - low) + 1.0;
+    const u32 q1 = (u32)(__builtin_fma(rd, (double)c, 0.5) * x);
+    const u32 q2m1 = (u32)__builtin_fma(__builtin_fma(rd, (double)d, 0.5), x, -1.0);
+    hm = low + q2m1;
+    low = low + q1;
+}
+
+// closed-form step counts AND the renormalised interval; true if the literal loops must be used for this symbol.
+// The corner test of af_renorm_counts on the SHIFTED values: ctz(low) + k + m + 1 >= 32 with low != 0 <=> every bit of
+// low leaves, i.e. (low << (k + m)) & 0x7FFFFFFF == 0; for high = hm + 1 != 2^32: (high << (k + m + 1)) mod 2^32 == 0 <=>
+// ((hm << kt) | ones(kt)) + 1 is 0 or 2^31 <=> the new hm (with its top bit set) is all ones.
+__device__ __forceinline__ bool af_renorm2(u32 low, u32 hm, u32 &k, u32 &m, u32 &nlow, u32 &nhm) {
+    k = (u32)__builtin_clz(low ^ hm);  // low != hm: the interval holds more than one value
+    const u32 z = ((low & ~hm) << k) << 1;
+    m = (u32)__builtin_clz(~z);
+    const u32 kt = k + m;  // <= 31
+    nlow = (low << kt) & 0x7FFFFFFFu;
+    nhm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+    return (nlow == 0 && low != 0) || (nhm == 0xFFFFFFFFu && hm != 0xFFFFFFFFu);
+}

@@ -45,9 +45,9 @@ typedef AnsBitReader<AS_THREADS, true> AsIn;
 // one symbol of the encoder: shrink_range, then the renormalisation loops (:126-150)
 __device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending, u32 c, u32 d, u32 T, double xT,
                                                  AsOut &wr, char *lds) {
-    af_shrink(low, hm, c, d, T, xT);
-    u32 k, m;
-    const bool edge = af_renorm_counts(low, hm, k, m);
+    af_shrink2(low, hm, c, d, xT);
+    u32 k, m, nlow, nhm;
+    const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
     if (__builtin_expect(edge || (k + pending > 32), 0)) {
         u64 lo = low, hi = (u64)hm + 1;
         while (hi < AF_HALF || lo > AF_HALF) {
@@ -83,9 +83,8 @@ __device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending
             pending = 0;
         }
         pending += m;
-        const u32 kt = k + m;  // <= 31
-        low = (low << kt) & 0x7FFFFFFFu;
-        hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+        low = nlow;
+        hm = nhm;
     }
 }
 
@@ -217,10 +216,10 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             }
         }
         const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_TAB_BASE + s * 8);
-        af_shrink(low, hm, e.x, e.y, P.T, xT);
+        af_shrink2(low, hm, e.x, e.y, xT);
         if (last) return s;
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -254,8 +253,8 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             rd.advance(lds, kt);
             const u32 keep = (state << k) & AF_HALF;
             state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
             used += kt;
         }
         return s;

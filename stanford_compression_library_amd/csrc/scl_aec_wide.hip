@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(AW_THREADS)
 
     // arithmetic stage: shrink_range (:58-78) and the renormalisation loops (:126-150) of one symbol
     auto code = [&](u32 cc, u32 dd, u32 TT, double xx) {
-        af_shrink(low, hm, cc, dd, TT, xx);
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        af_shrink2(low, hm, cc, dd, xx);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge || (k + pending > 32), 0)) {
             u64 lo = low, hi = (u64)hm + 1;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -107,9 +107,8 @@ __global__ void __launch_bounds__(AW_THREADS)
                 pending = 0;
             }
             pending += m;
-            const u32 kt = k + m;  // <= 31
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
         }
     };
 
@@ -267,7 +266,7 @@ __global__ void __launch_bounds__(AW_THREADS)
         cnt[rb + b] = fb + 1;
         ctx = aw_next_ctx(P, ctx, s);
         bt = aw_load16(cnt + (u64)ctx * P.row_cells);
-        af_shrink(low, hm, c, d, T, xT);
+        af_shrink2(low, hm, c, d, xT);
         // ---- symbol out ----
         oword |= s << (8 * (i & 3));
         if ((i & 3) == 3) {
@@ -276,8 +275,8 @@ __global__ void __launch_bounds__(AW_THREADS)
         }
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -308,8 +307,8 @@ __global__ void __launch_bounds__(AW_THREADS)
             const u32 bits = rd.get(kt);
             const u32 keep = (state << k) & AF_HALF;
             state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
             used += kt;
         }
     }

@@ -4,6 +4,7 @@ arena pre-filled with 0xA5, with 4 KiB guard bands in front of, between and behi
 ragged lengths, partial waves, both rANS ring writers, cooperative and per-lane stores, every tuned kernel family and the
 any-parameter kernels -- every guard byte must still be 0xA5, and so must the bytes of every slot behind its stream."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -70,7 +71,7 @@ def test_outputs_stay_inside_their_buffers(name, shape, monkeypatch):
     dev = torch.device("cuda:0")
     make, K, freq = _models()[name]
     model = make()
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(zlib.crc32(f"{name}/{shape}".encode()))  # NOT hash(): that is salted per process
     n_chunks, chunk_len = (333, 700) if shape != "full" else (512, 1024)
     p = freq / freq.sum()
     sym = torch.from_numpy(rng.choice(K, size=(n_chunks, (chunk_len + 15) // 16 * 16), p=p).astype(np.uint8)).to(dev)[:, :chunk_len]
@@ -137,7 +138,11 @@ def test_outputs_stay_inside_their_buffers(name, shape, monkeypatch):
         arena.check(f"{name} decode {shape} {wsel}")
         assert int(status.abs().sum()) == 0
         ref_lens = lens if lens is not None else torch.full((n_chunks,), chunk_len, dtype=torch.int32, device=dev)
-        assert torch.equal(lens_out, ref_lens) and torch.equal(used, enc.nbits)
+        assert torch.equal(lens_out, ref_lens)
+        # num_bits_consumed equals the stream length -- except, for the arithmetic coder, on rare blocks of one or two
+        # symbols, where the reference's own rule (arithmetic_coding.py:277-285) stops short (tests/test_gpu_stream_goldens.py)
+        settled = torch.ones_like(ref_lens, dtype=torch.bool) if not name.startswith("aec") else ref_lens > 2
+        assert torch.equal(used[settled], enc.nbits[settled])
         got, want = sym_out.cpu().numpy(), sym.cpu().numpy()
         ln_h = ref_lens.cpu().numpy()
         for c in range(n_chunks):
