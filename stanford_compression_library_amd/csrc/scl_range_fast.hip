@@ -136,10 +136,13 @@ struct RgDivM {
     double inv_m;
 };
 // MODE: 0 = power-of-two total, 1 = any total, 2 = power-of-two total shared evenly by 256 symbols (f = 2^t, c = s f:
-// no table at all -- configs[2], uniform bytes with f = 1, is the t = 0 case)
+// no table at all), 3 = the same with t = 0 as a compile-time fact (f = 1, M = 256: configs[2], uniform bytes -- two
+// shifts by zero less per decoded symbol, one per encoded symbol)
+#define RG_UNI(MODE) ((MODE) == 2 || (MODE) == 3)
 template <int MODE>
 __device__ __forceinline__ u32 rg_range_over_m(u32 range, const RgDivM &md) {
     if (MODE == 1) return (u32)(((double)range + 0.5) * md.inv_m);
+    if (MODE == 3) return range >> 8;  // a literal shift: half the cost of one whose amount sits in an SGPR
     return range >> md.m_log2;
 }
 
@@ -163,8 +166,8 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
                                                  u32 &nb, u32 &pb, u32 &pn, RgOut &o, char *lds) {
     const u32 r = rg_range_over_m<MODE>(range, md);
     u32 low0, range0;
-    if (MODE == 2) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
-        range0 = r << md.t;
+    if (RG_UNI(MODE)) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
+        range0 = (MODE == 3) ? r : (r << md.t);
         low0 = __umul24(e.x, range0) + low;
     } else {
         low0 = low + e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
@@ -219,7 +222,7 @@ struct RgLine128 {
 // table entry {c, f} of the symbol whose byte offset into the table is a (= symbol * 8); MODE 2 has no table
 template <int MODE>
 __device__ __forceinline__ uint2 rg_entry(const char *tab, u32 a) {
-    if (MODE == 2) return make_uint2(a >> 3, 0u);
+    if (RG_UNI(MODE)) return make_uint2(a >> 3, 0u);
     return *reinterpret_cast<const uint2 *>(tab + a);
 }
 
@@ -442,8 +445,8 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     q = min(q, slot_max);  // state in the slack above c[K-1] + f[K-1] maps to the last symbol
     u32 s;
     uint2 e;
-    if (MODE == 2) {  // the slot IS the symbol (times f): no table read on the serial chain
-        s = q >> md.t;
+    if (RG_UNI(MODE)) {  // the slot IS the symbol (times f): no table read on the serial chain
+        s = (MODE == 3) ? q : (q >> md.t);
         e = make_uint2(0u, 0u);
     } else if (LUT) {  // one read: slot -> {c | s << 24, f}
         e = *reinterpret_cast<const uint2 *>(tab + q * 8);
@@ -459,8 +462,8 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         }
         e = *reinterpret_cast<const uint2 *>(tab + s * 8);
     }
-    if (MODE == 2) {
-        const u32 rf = rr << md.t;  // < 2^24, see rg_encode_symbol
+    if (RG_UNI(MODE)) {
+        const u32 rf = (MODE == 3) ? rr : (rr << md.t);  // < 2^24, see rg_encode_symbol
         low = __umul24(s, rf) + low;
         range = rf;
     } else {
@@ -639,7 +642,8 @@ void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym
 #define RG_LAUNCH_ENC(MODE)                                                                                      \
     hipLaunchKernelGGL(range_encode_fast_kernel<MODE>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,       \
                        sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
-    if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_ENC(2);
+    if (m->fdev.uni_t == 0) RG_LAUNCH_ENC(3);
+    else if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_ENC(2);
     else if (m->fdev.m_log2 != 0xFFFFFFFFu) RG_LAUNCH_ENC(0);
     else RG_LAUNCH_ENC(1);
 #undef RG_LAUNCH_ENC
@@ -661,7 +665,8 @@ void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_s
         else RG_LAUNCH_DEC2(MODE, LUT, false);                         \
     } while (0)
     const bool pow2 = m->fdev.m_log2 != 0xFFFFFFFFu, lut = m->fdev.M <= 4096;
-    if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_DEC2(2, true, true);
+    if (m->fdev.uni_t == 0) RG_LAUNCH_DEC2(3, true, true);
+    else if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_DEC2(2, true, true);
     else if (pow2 && lut) RG_LAUNCH_DEC(0, true);
     else if (pow2) RG_LAUNCH_DEC(0, false);
     else if (lut) RG_LAUNCH_DEC(1, true);
