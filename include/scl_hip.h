@@ -27,8 +27,9 @@
  *   - pointers named d_* are DEVICE pointers (HBM) owned by the caller; h_* are host pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
  *     on that stream; nothing synchronises unless stated.
- *   - symbols are uint8 alphabet indices (position in Frequencies.freq_dict, prob_dist.py:193-205);
- *     alphabets are limited to 256 entries.
+ *   - symbols are alphabet indices (position in Frequencies.freq_dict, prob_dist.py:193-205): uint8 for alphabets
+ *     up to 256 entries -- the entry points BASELINE.json's configurations use, served by the tuned kernels -- and
+ *     uint16 for alphabets up to 65536 through the *_u16 twins at the end of this header (any-parameter kernels).
  *   - a bit stream is MSB-first packed bytes (bitarray "big" endianness, bitarray_utils.py:25).
  *     A stream is described by (bit_offset, nbits): bit_offset is the absolute position of its
  *     first bit counted from the buffer's base pointer.  Encoders WRITE these descriptors;
@@ -96,8 +97,8 @@ typedef struct scl_rans_info {
 } scl_rans_info;
 
 /* rANSParams(freqs, DATA_BLOCK_SIZE_BITS, NUM_BITS_OUT, RANGE_FACTOR) -> device-resident tables.
-   Rejects: K == 0 or > 256, any freq == 0, H >= 2^63 (quirks Q7/Q8), size_bits or num_bits_out
-   outside 1..32. */
+   Rejects: K == 0 or > 65536, any freq == 0, H >= 2^63 (quirks Q7/Q8), size_bits or num_bits_out
+   outside 1..32.  Models of more than 256 symbols are coded through the *_u16 entry points. */
 int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor,
                           uint32_t num_bits_out, uint32_t size_bits, scl_rans_model **out);
 void scl_rans_model_destroy(scl_rans_model *m);
@@ -338,6 +339,85 @@ int scl_aec_decode_host_resume(const scl_aec_model *m, const uint8_t *h_in, uint
 /* peek the DATA_BLOCK_SIZE_BITS header of a host stream (so callers can size h_out_sym) */
 int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
                                uint64_t *n_out);
+
+/* ---- alphabets of up to 65536 symbols: uint16 symbol indices (ABI 4) ---------------------------------
+ * The reference codes any hashable alphabet (Frequencies.freq_dict, prob_dist.py:193-205); its LZ77 / text models
+ * reach past 256 symbols.  Every batch / host entry point above has a *_u16 twin with the same arguments, the
+ * symbol arrays typed uint16_t and the symbol strides counted in SYMBOLS.  They take ANY model handle (models of
+ * more than 256 symbols are refused by the uint8 entry points with SCL_E_PARAM) and run the any-parameter kernels:
+ * tables are read where they are in device memory, adaptive order-k / i.i.d. rows are scanned linearly (cost per
+ * symbol grows with the alphabet).  For a model of at most 256 symbols the stream equals the uint8 entry point's. */
+int scl_rans_encode_batch_u16(const scl_rans_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                              const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                              uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                              uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_rans_decode_batch_u16(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                              const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                              uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                              uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                              uint32_t *d_status, void *stream);
+int scl_tans_encode_batch_u16(const scl_tans_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                              const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                              uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                              uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_tans_decode_batch_u16(const scl_tans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                              const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                              uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                              uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                              uint32_t *d_status, void *stream);
+int scl_range_encode_batch_u16(const scl_range_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                               const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                               uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                               uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_range_decode_batch_u16(const scl_range_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                               const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                               uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                               uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                               uint32_t *d_status, void *stream);
+int scl_aec_encode_batch_u16(const scl_aec_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                             const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                             uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                             uint32_t *d_out_nbits, uint32_t *d_status, void *d_scratch,
+                             uint64_t scratch_bytes, void *stream);
+int scl_aec_decode_batch_u16(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                             const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                             uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                             uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                             uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes,
+                             void *stream);
+int scl_aec_encode_batch_resume_u16(const scl_aec_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                                    const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                    uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                    uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
+                                    uint64_t state_bytes, uint64_t n_coders, void *stream);
+int scl_aec_decode_batch_resume_u16(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                    const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                    uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                                    uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                    uint32_t *d_status, void *d_state, uint64_t state_bytes, uint64_t n_coders,
+                                    void *stream);
+int scl_rans_encode_host_u16(const scl_rans_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                             uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_rans_decode_host_u16(const scl_rans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                             uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_tans_encode_host_u16(const scl_tans_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                             uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_tans_decode_host_u16(const scl_tans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                             uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_range_encode_host_u16(const scl_range_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                              uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_range_decode_host_u16(const scl_range_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                              uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_aec_encode_host_u16(const scl_aec_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                            uint64_t out_cap_bytes, uint64_t *nbits);
+int scl_aec_decode_host_u16(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                            uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed);
+int scl_aec_encode_host_resume_u16(const scl_aec_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                                   uint64_t out_cap_bytes, uint64_t *nbits, uint32_t *h_counts,
+                                   uint32_t *h_past_k);
+int scl_aec_decode_host_resume_u16(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                   uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed,
+                                   uint32_t *h_counts, uint32_t *h_past_k);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ def add_coder_case(col, kind, meta, alphabet, idx_syms, make_encoder, make_decod
     data = DataBlock([alphabet[i] for i in idx_syms])
     enc_bits = make_encoder().encode_block(data)
     packed, nbits = pack(enc_bits)
-    arrays = dict(sym=np.asarray(idx_syms, dtype=np.uint8), out=packed)
+    arrays = dict(sym=np.asarray(idx_syms, dtype=np.uint16 if len(alphabet) > 256 else np.uint8), out=packed)
     meta = dict(meta, kind=kind, n=len(idx_syms), nbits=nbits)
     if decode:
         garb, consumed = trailing_checks(make_decoder, enc_bits, rng, idx_syms, alphabet)
@@ -503,9 +503,65 @@ def gen_stream(col, rng):
                 text=np.frombuffer(text.encode("ascii"), dtype=np.uint8), file=np.fromfile(dst, dtype=np.uint8))
 
 
+# ------------------------------------------------------------------------------------------------
+# G11: alphabets of more than 256 symbols (golden_wide.npz; symbol indices stored as uint16).  The reference codes any
+# hashable alphabet; these pin the uint16 entry points (the *_u16 twins of include/scl_hip.h, the *_w16 oracle functions).
+def gen_wide(col, rng):
+    def table(K, lo, hi, seed):
+        return [int(v) for v in np.random.default_rng(seed).integers(lo, hi, K)]
+
+    # rANS: K = 300 with the default parameters, K = 1000 with NUM_BITS_OUT = 2 and a small RANGE_FACTOR
+    for K, kw, n in ((300, {}, 600), (1000, dict(NUM_BITS_OUT=2, RANGE_FACTOR=1 << 4), 700)):
+        fl = table(K, 1, 30, K)
+        alphabet = list(range(K))
+        fr = Frequencies(dict(zip(alphabet, fl)))
+        p = rANSParams(fr, **kw)
+        syms = np.random.default_rng(K + 1).integers(0, K, n)
+        add_coder_case(col, "rans", dict(group="G11", freq=fl, RF=p.RANGE_FACTOR, b=p.NUM_BITS_OUT,
+                                         size_bits=p.DATA_BLOCK_SIZE_BITS), alphabet, syms,
+                       lambda: rANSEncoder(p), lambda: rANSDecoder(p), rng)
+    # tANS: K = 512, M = 1024 (a power of two), RANGE_FACTOR = 2; the stream equals rANS with the same parameters
+    K = 512
+    fl = [1] * K
+    for i in np.random.default_rng(7).integers(0, K, 512):
+        fl[int(i)] += 1
+    alphabet = list(range(K))
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    tp = tANSParams(fr, RANGE_FACTOR=2)
+    syms = iid_indices(fl, 600, seed=8).astype(np.int64)
+    bits = add_coder_case(col, "tans", dict(group="G11", freq=fl, RF=2, size_bits=tp.DATA_BLOCK_SIZE_BITS), alphabet,
+                          syms, lambda: tANSEncoder(tp), lambda: tANSDecoder(tp), rng)
+    assert bits == rANSEncoder(rANSParams(fr, RANGE_FACTOR=2)).encode_block(DataBlock([int(v) for v in syms]))
+    # range coder: K = 700
+    K = 700
+    fl = table(K, 1, 40, 9)
+    alphabet = list(range(K))
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    rp = RangeCoderParams()
+    syms = np.random.default_rng(10).integers(0, K, 600)
+    add_coder_case(col, "range", dict(group="G11", freq=fl, precision=rp.PRECISION, size_bits=rp.DATA_BLOCK_SIZE_BITS),
+                   alphabet, syms, lambda: RangeEncoder(rp, fr), lambda: RangeDecoder(rp, fr), rng)
+    # arithmetic coder: fixed / adaptive i.i.d. / order-1 on K = 300
+    K = 300
+    fl = table(K, 1, 25, 11)
+    alphabet = list(range(K))
+    ap = AECParams()
+    syms = np.random.default_rng(12).integers(0, K, 400)
+    fr = Frequencies(dict(zip(alphabet, fl)))
+    ones = Frequencies(dict(zip(alphabet, [1] * K)))
+    models = (("fixed", fl, 0, lambda: FixedFreqModel(fr, ap.MAX_ALLOWED_TOTAL_FREQ)),
+              ("iid", [1] * K, 0, lambda: AdaptiveIIDFreqModel(ones, ap.MAX_ALLOWED_TOTAL_FREQ)),
+              ("orderk", [1] * K, 1, lambda: AdaptiveOrderKFreqModel(alphabet, 1, ap.MAX_ALLOWED_TOTAL_FREQ)))
+    for model_name, init, k, mk in models:
+        add_coder_case(col, "aec", dict(group="G11", model=model_name, freq=init, K=K, k=k,
+                                        max_total=ap.MAX_ALLOWED_TOTAL_FREQ, precision=ap.PRECISION,
+                                        size_bits=ap.DATA_BLOCK_SIZE_BITS), alphabet, syms,
+                       lambda: ArithmeticEncoder(ap, mk()), lambda: ArithmeticDecoder(ap, mk()), rng)
+
+
 def main(out_dir):
     for name, fn in (("rans", gen_rans), ("tans", gen_tans), ("range", gen_range), ("aec", gen_aec),
-                     ("stream", gen_stream)):
+                     ("stream", gen_stream), ("wide", gen_wide)):
         col = Collector()
         fn(col, np.random.default_rng(12345))
         col.save(f"{out_dir}/golden_{name}.npz")

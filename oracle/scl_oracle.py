@@ -57,6 +57,14 @@ def lib():
         L.orc_aec_decode_st.argtypes = L.orc_aec_decode.argtypes + [u64p]
         L.orc_rans_encode_batch.argtypes = [u8p, u64, u64, u32p, u32, u64, u32, u32, u8p, u64, u64p]
         L.orc_rans_decode_batch.argtypes = [u8p, u64, u64, u64p, u32p, u32, u64, u32, u32, u8p, u64, u64p]
+        u16p = C.POINTER(C.c_uint16)
+        for base, sym_arg in (("orc_rans_encode", 0), ("orc_rans_decode", 7), ("orc_tans_encode", 0),
+                              ("orc_tans_decode", 6), ("orc_range_encode", 0), ("orc_range_decode", 6),
+                              ("orc_aec_encode_st", 0), ("orc_aec_decode_st", 9)):
+            at = list(getattr(L, base).argtypes)
+            at[sym_arg] = u16p  # the symbol array: uint16 indices (alphabets up to 65536)
+            getattr(L, base + "_w16").argtypes = at
+            getattr(L, base + "_w16").restype = i64
         for name in ("orc_rans_encode", "orc_rans_decode", "orc_tans_encode", "orc_tans_decode",
                      "orc_tans_tables", "orc_range_encode", "orc_range_decode", "orc_aec_encode",
                      "orc_aec_decode", "orc_aec_encode_st", "orc_aec_decode_st", "orc_rans_encode_batch",
@@ -78,6 +86,16 @@ def _freq(f):
     return np.ascontiguousarray(f, dtype=np.uint32)
 
 
+def _syms(a, K, wide):
+    """symbol array -> (contiguous array, ctypes type, "_w16" or ""): uint16 indices when the alphabet has more
+    than 256 symbols (or the caller asks for them), uint8 otherwise"""
+    if wide is None:
+        wide = K > 256
+    if wide:
+        return np.ascontiguousarray(a, dtype=np.uint16), C.c_uint16, "_w16"
+    return np.ascontiguousarray(a, dtype=np.uint8), C.c_uint8, ""
+
+
 def _check(rc, what):
     if rc < 0:
         raise OracleError(int(rc), what)
@@ -89,38 +107,40 @@ def _enc_out(n, bits_per_sym=64, extra=64):
 
 
 # ---- rANS ------------------------------------------------------------------------------------
-def rans_encode(sym, freq, RF=1 << 16, b=1, size_bits=32):
-    sym, f = _u8(sym), _freq(freq)
+def rans_encode(sym, freq, RF=1 << 16, b=1, size_bits=32, wide=None):
+    f = _freq(freq)
+    sym, ct, sfx = _syms(sym, f.size, wide)
     out = _enc_out(sym.size)
-    nb = _check(lib().orc_rans_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, RF, b,
+    nb = _check(getattr(lib(), "orc_rans_encode" + sfx)(_p(sym, ct), sym.size, _p(f, C.c_uint32), f.size, RF, b,
                                       size_bits, _p(out, C.c_uint8), out.size), "rans_encode")
     return out[: (nb + 7) // 8].copy(), nb
 
 
-def rans_decode(packed, nbits, freq, RF=1 << 16, b=1, size_bits=32, cap=1 << 22):
+def rans_decode(packed, nbits, freq, RF=1 << 16, b=1, size_bits=32, cap=1 << 22, wide=None):
     buf, f = _u8(packed), _freq(freq)
-    out = np.zeros(cap, dtype=np.uint8)
+    out, ct, sfx = _syms(np.zeros(cap, dtype=np.uint16), f.size, wide)
     n = C.c_uint64(0)
-    used = _check(lib().orc_rans_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF, b,
-                                        size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "rans_decode")
+    used = _check(getattr(lib(), "orc_rans_decode" + sfx)(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF, b,
+                                                          size_bits, _p(out, ct), cap, C.byref(n)), "rans_decode")
     return out[: n.value].copy(), used
 
 
 # ---- tANS ------------------------------------------------------------------------------------
-def tans_encode(sym, freq, RF=1 << 16, size_bits=32):
-    sym, f = _u8(sym), _freq(freq)
+def tans_encode(sym, freq, RF=1 << 16, size_bits=32, wide=None):
+    f = _freq(freq)
+    sym, ct, sfx = _syms(sym, f.size, wide)
     out = _enc_out(sym.size)
-    nb = _check(lib().orc_tans_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, RF,
+    nb = _check(getattr(lib(), "orc_tans_encode" + sfx)(_p(sym, ct), sym.size, _p(f, C.c_uint32), f.size, RF,
                                       size_bits, _p(out, C.c_uint8), out.size), "tans_encode")
     return out[: (nb + 7) // 8].copy(), nb
 
 
-def tans_decode(packed, nbits, freq, RF=1 << 16, size_bits=32, cap=1 << 22):
+def tans_decode(packed, nbits, freq, RF=1 << 16, size_bits=32, cap=1 << 22, wide=None):
     buf, f = _u8(packed), _freq(freq)
-    out = np.zeros(cap, dtype=np.uint8)
+    out, ct, sfx = _syms(np.zeros(cap, dtype=np.uint16), f.size, wide)
     n = C.c_uint64(0)
-    used = _check(lib().orc_tans_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF,
-                                        size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "tans_decode")
+    used = _check(getattr(lib(), "orc_tans_decode" + sfx)(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, RF,
+                                                          size_bits, _p(out, ct), cap, C.byref(n)), "tans_decode")
     return out[: n.value].copy(), used
 
 
@@ -138,20 +158,22 @@ def tans_tables(freq, RF=1):
 
 
 # ---- range coder -----------------------------------------------------------------------------
-def range_encode(sym, freq, precision=32, size_bits=32):
-    sym, f = _u8(sym), _freq(freq)
+def range_encode(sym, freq, precision=32, size_bits=32, wide=None):
+    f = _freq(freq)
+    sym, ct, sfx = _syms(sym, f.size, wide)
     out = _enc_out(sym.size)
-    nb = _check(lib().orc_range_encode(_p(sym, C.c_uint8), sym.size, _p(f, C.c_uint32), f.size, precision,
+    nb = _check(getattr(lib(), "orc_range_encode" + sfx)(_p(sym, ct), sym.size, _p(f, C.c_uint32), f.size, precision,
                                        size_bits, _p(out, C.c_uint8), out.size), "range_encode")
     return out[: (nb + 7) // 8].copy(), nb
 
 
-def range_decode(packed, nbits, freq, precision=32, size_bits=32, cap=1 << 22):
+def range_decode(packed, nbits, freq, precision=32, size_bits=32, cap=1 << 22, wide=None):
     buf, f = _u8(packed), _freq(freq)
-    out = np.zeros(cap, dtype=np.uint8)
+    out, ct, sfx = _syms(np.zeros(cap, dtype=np.uint16), f.size, wide)
     n = C.c_uint64(0)
-    used = _check(lib().orc_range_decode(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size, precision,
-                                         size_bits, _p(out, C.c_uint8), cap, C.byref(n)), "range_decode")
+    used = _check(getattr(lib(), "orc_range_decode" + sfx)(_p(buf, C.c_uint8), nbits, _p(f, C.c_uint32), f.size,
+                                                           precision, size_bits, _p(out, ct), cap, C.byref(n)),
+                  "range_decode")
     return out[: n.value].copy(), used
 
 
@@ -174,25 +196,27 @@ def _state_ptr(state):
     return _p(state, C.c_uint64)
 
 
-def aec_encode(sym, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32, size_bits=32, state=None):
-    sym = _u8(sym)
+def aec_encode(sym, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32, size_bits=32, state=None,
+               wide=None):
+    sym, ct, sfx = _syms(sym, K, wide)
     f = _freq(f_init if f_init is not None else np.ones(K))
     out = _enc_out(sym.size, bits_per_sym=96, extra=256)
-    nb = _check(lib().orc_aec_encode_st(_p(sym, C.c_uint8), sym.size, model_kind, K, k, _p(f, C.c_uint32),
+    nb = _check(getattr(lib(), "orc_aec_encode_st" + sfx)(_p(sym, ct), sym.size, model_kind, K, k, _p(f, C.c_uint32),
                                         max_total, precision, size_bits, _p(out, C.c_uint8), out.size,
                                         _state_ptr(state)), "aec_encode")
     return out[: (nb + 7) // 8].copy(), nb
 
 
 def aec_decode(packed, nbits, model_kind, K, k=0, f_init=None, max_total=1 << 30, precision=32,
-               size_bits=32, cap=1 << 22, state=None):
+               size_bits=32, cap=1 << 22, state=None, wide=None):
     buf = _u8(packed)
     f = _freq(f_init if f_init is not None else np.ones(K))
-    out = np.zeros(cap, dtype=np.uint8)
+    out, ct, sfx = _syms(np.zeros(cap, dtype=np.uint16), K, wide)
     n = C.c_uint64(0)
-    used = _check(lib().orc_aec_decode_st(_p(buf, C.c_uint8), nbits, model_kind, K, k, _p(f, C.c_uint32),
-                                          max_total, precision, size_bits, _p(out, C.c_uint8), cap,
-                                          C.byref(n), _state_ptr(state)), "aec_decode")
+    used = _check(getattr(lib(), "orc_aec_decode_st" + sfx)(_p(buf, C.c_uint8), nbits, model_kind, K, k,
+                                                            _p(f, C.c_uint32), max_total, precision, size_bits,
+                                                            _p(out, ct), cap, C.byref(n), _state_ptr(state)),
+                  "aec_decode")
     return out[: n.value].copy(), used
 
 

@@ -105,6 +105,17 @@ _SIGNATURES = {
     "scl_streams_gatherv_rccl": (_int, [_vp, _int, _u32, C.POINTER(_vp), _u64p, C.POINTER(_vp), _u64p, _vp]),
 }
 
+# the *_u16 twins (alphabets up to 65536 symbols): same arguments, symbol arrays are uint16; host arrays travel as void*
+_ENC_HOST16 = [_vp, _vp, _u64, _u8p, _u64, _u64p]
+_DEC_HOST16 = [_vp, _u8p, _u64, _vp, _u64, _u64p, _u64p]
+for _coder in ("rans", "tans", "range", "aec"):
+    for _op, _host in (("encode", _ENC_HOST16), ("decode", _DEC_HOST16)):
+        _SIGNATURES[f"scl_{_coder}_{_op}_batch_u16"] = _SIGNATURES[f"scl_{_coder}_{_op}_batch"]
+        _SIGNATURES[f"scl_{_coder}_{_op}_host_u16"] = (_int, _host)
+for _op, _host in (("encode", _ENC_HOST16), ("decode", _DEC_HOST16)):
+    _SIGNATURES[f"scl_aec_{_op}_batch_resume_u16"] = _SIGNATURES[f"scl_aec_{_op}_batch_resume"]
+    _SIGNATURES[f"scl_aec_{_op}_host_resume_u16"] = (_int, _host + [_u32p, _u32p])
+
 _lib = None
 _lock = threading.Lock()
 

@@ -65,10 +65,32 @@ class _DeviceModel:
 
     _prefix = ""
     _needs_scratch = False
+    K = 0  # alphabet size; above 256 the symbols travel as uint16 indices through the *_u16 entry points
 
     def __init__(self):
         self._h = C.c_void_p()
         self._L = _lib.load()
+
+    @property
+    def wide(self) -> bool:
+        return self.K > 256
+
+    @property
+    def sym_dtype(self):
+        """numpy dtype of this model's symbol index arrays"""
+        return np.uint16 if self.wide else np.uint8
+
+    def _torch_sym_dtypes(self):
+        import torch
+
+        return (torch.uint16, torch.int16) if self.wide else (torch.uint8,)
+
+    def _sym_fn(self, name):
+        """entry point that takes / returns symbol arrays: the *_u16 twin for alphabets above 256"""
+        return getattr(self._L, f"scl_{self._prefix}_{name}" + ("_u16" if self.wide else ""))
+
+    def _host_ptr(self, a: np.ndarray):
+        return C.c_void_p(a.ctypes.data) if self.wide else _lib.u8_ptr(a)
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -90,25 +112,25 @@ class _DeviceModel:
 
     # -- one chunk, host memory -------------------------------------------------------------------
     def encode_host(self, sym: np.ndarray):
-        """uint8 index array -> (packed MSB-first bytes, nbits), left-aligned like BitArray.tobytes()."""
-        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        """index array (``sym_dtype``) -> (packed MSB-first bytes, nbits), left-aligned like BitArray.tobytes()."""
+        sym = np.ascontiguousarray(sym, dtype=self.sym_dtype)
         cap = self.slot_bytes(sym.size) + 16
         out = np.zeros(cap, dtype=np.uint8)
         nbits = C.c_uint64(0)
-        rc = self._fn("encode_host")(self._h, _lib.u8_ptr(sym), sym.size, _lib.u8_ptr(out), cap, C.byref(nbits))
+        rc = self._sym_fn("encode_host")(self._h, self._host_ptr(sym), sym.size, _lib.u8_ptr(out), cap, C.byref(nbits))
         _lib.check(rc, f"scl_{self._prefix}_encode_host")
         return out[: (nbits.value + 7) // 8], int(nbits.value)
 
     def decode_host(self, packed: np.ndarray, nbits: int, size_bits: int):
-        """(packed bytes, available bits) -> (uint8 index array, num_bits_consumed)."""
+        """(packed bytes, available bits) -> (index array of ``sym_dtype``, num_bits_consumed)."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
-        out = np.zeros(max(int(n.value), 1), dtype=np.uint8)
+        out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
-        rc = self._fn("decode_host")(self._h, _lib.u8_ptr(packed), int(nbits), _lib.u8_ptr(out), int(n.value),
-                                     C.byref(n_out), C.byref(used))
+        rc = self._sym_fn("decode_host")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out), int(n.value),
+                                         C.byref(n_out), C.byref(used))
         _lib.check(rc, f"scl_{self._prefix}_decode_host")
         return out[: n_out.value], int(used.value)
 
@@ -156,7 +178,7 @@ class _DeviceModel:
         the tuned kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call)."""
         import torch
 
-        assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
+        assert sym.is_cuda and sym.dtype in self._torch_sym_dtypes() and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
         dev = sym.device
         # rows that do not start on 16-byte boundaries are re-laid INSIDE the library (RowRelay, csrc/scl_core.hip)
@@ -174,7 +196,7 @@ class _DeviceModel:
             self._keep_scratch(st, scratch)
         with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
             # the library launches on the CURRENT device and checks it is the model's
-            rc = self._fn("encode_batch")(*args, st)
+            rc = self._sym_fn("encode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
         return out
 
@@ -187,6 +209,7 @@ class _DeviceModel:
         n_rows, chunk_len = sym.shape
         assert 0 <= a <= b <= n_rows == out.n_chunks and sym.stride(1) == 1
         assert sym.stride(0) % 16 == 0 and sym.data_ptr() % 16 == 0, "rows must start on 16-byte boundaries"
+        assert not self.wide, "the overlapped pipeline carries uint8 symbols"
         args = [self._h, sym.data_ptr() + a * sym.stride(0), sym.stride(0), None, chunk_len, b - a,
                 out.data.data_ptr() + a * out.stride, out.stride, out.bit_offset.data_ptr() + 8 * a,
                 out.nbits.data_ptr() + 4 * a, out.status.data_ptr() + 4 * a]
@@ -202,7 +225,7 @@ class _DeviceModel:
         import torch
 
         out_stride = (int(chunk_cap) + 15) // 16 * 16
-        return (torch.empty((n_chunks, out_stride), dtype=torch.uint8, device=device),
+        return (torch.empty((n_chunks, out_stride), dtype=self._torch_sym_dtypes()[0], device=device),
                 torch.empty(n_chunks, dtype=torch.int32, device=device),
                 torch.empty(n_chunks, dtype=torch.int32, device=device),
                 torch.empty(n_chunks, dtype=torch.int32, device=device))
@@ -227,7 +250,7 @@ class _DeviceModel:
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
             self._keep_scratch(st, scratch)
         with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
-            rc = self._fn("decode_batch")(*args, st)
+            rc = self._sym_fn("decode_batch")(*args, st)
         _lib.check(rc, f"scl_{self._prefix}_decode_batch")
         return sym[:, :chunk_cap], lens, used, status
 
@@ -242,6 +265,7 @@ class RansModel(_DeviceModel):
                                            int(size_bits), C.byref(self._h))
         _lib.check(rc, "scl_rans_model_create")
         self.size_bits = int(size_bits)
+        self.K = int(f.size)
 
     def info(self) -> _lib.RansInfo:
         info = _lib.RansInfo()
@@ -287,6 +311,7 @@ class RangeModel(_DeviceModel):
                                             C.byref(self._h))
         _lib.check(rc, "scl_range_model_create")
         self.size_bits = int(size_bits)
+        self.K = int(f.size)
 
     def fast_path(self) -> bool:
         """True if the tuned kernels (scl_range_fast.hip) serve this model."""
@@ -305,6 +330,7 @@ class AecModel(_DeviceModel):
                                           int(precision), int(size_bits), C.byref(self._h))
         _lib.check(rc, "scl_aec_model_create")
         self.size_bits = int(size_bits)
+        self.K = int(K)
 
     def fast_path(self, max_symbols: int) -> bool:
         """True if chunks of up to max_symbols symbols run on the per-lane-LDS-table kernels (scl_aec_fast.hip)."""
@@ -316,12 +342,12 @@ class AecModel(_DeviceModel):
 
     def encode_host_resume(self, sym: np.ndarray, counts: np.ndarray, past_k: np.ndarray):
         """one block of a coder whose model state is (counts, past_k); both arrays are updated in place"""
-        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        sym = np.ascontiguousarray(sym, dtype=self.sym_dtype)
         assert counts.dtype == np.uint32 and past_k.dtype == np.uint32 and counts.flags.c_contiguous
         cap = self.slot_bytes(sym.size) + 16
         out = np.zeros(cap, dtype=np.uint8)
         nbits = C.c_uint64(0)
-        rc = self._L.scl_aec_encode_host_resume(self._h, _lib.u8_ptr(sym), sym.size, _lib.u8_ptr(out), cap,
+        rc = self._sym_fn("encode_host_resume")(self._h, self._host_ptr(sym), sym.size, _lib.u8_ptr(out), cap,
                                                 C.byref(nbits), _lib.u32_ptr(counts), _lib.u32_ptr(past_k))
         _lib.check(rc, "scl_aec_encode_host_resume")
         return out[: (nbits.value + 7) // 8], int(nbits.value)
@@ -333,9 +359,9 @@ class AecModel(_DeviceModel):
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
-        out = np.zeros(max(int(n.value), 1), dtype=np.uint8)
+        out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
-        rc = self._L.scl_aec_decode_host_resume(self._h, _lib.u8_ptr(packed), int(nbits), _lib.u8_ptr(out),
+        rc = self._sym_fn("decode_host_resume")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out),
                                                 int(n.value), C.byref(n_out), C.byref(used), _lib.u32_ptr(counts),
                                                 _lib.u32_ptr(past_k))
         _lib.check(rc, "scl_aec_decode_host_resume")
@@ -383,14 +409,14 @@ class AecModel(_DeviceModel):
         """chunk c CONTINUES coder c of ``state`` (from :meth:`alloc_state`) and leaves the advanced state there"""
         import torch
 
-        assert sym.is_cuda and sym.dtype == torch.uint8 and sym.dim() == 2 and sym.stride(1) == 1
+        assert sym.is_cuda and sym.dtype in self._torch_sym_dtypes() and sym.dim() == 2 and sym.stride(1) == 1
         n_chunks, chunk_len = sym.shape
         n_coders = self._state_coders(state, n_chunks)
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, sym.device, out_stride)
         st = stream if stream is not None else torch.cuda.current_stream(sym.device).cuda_stream
         with torch.cuda.device(sym.device):
-            rc = self._L.scl_aec_encode_batch_resume(
+            rc = self._sym_fn("encode_batch_resume")(
                 self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None, chunk_len,
                 n_chunks, out.data.data_ptr(), out.stride, out.bit_offset.data_ptr(), out.nbits.data_ptr(),
                 out.status.data_ptr(), state.data_ptr(), state.numel(), n_coders, st)
@@ -406,7 +432,7 @@ class AecModel(_DeviceModel):
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = self._L.scl_aec_decode_batch_resume(
+            rc = self._sym_fn("decode_batch_resume")(
                 self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
                 sym.data_ptr(), sym.stride(0), int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr(),
                 state.data_ptr(), state.numel(), n_coders, st)

@@ -7,13 +7,18 @@ from ..core.data_block import DataBlock
 from ..utils.bitarray_utils import BitArray
 
 
+def index_dtype(alphabet_size: int):
+    """uint8 indices for alphabets up to 256 symbols (the tuned kernels), uint16 up to 65536 (the *_u16 entry points)"""
+    return np.uint16 if alphabet_size > 256 else np.uint8
+
+
 def symbols_to_indices(data_block: DataBlock, index_of: dict) -> np.ndarray:
-    """Map a block's symbols to uint8 alphabet indices; an unknown symbol raises ``KeyError`` exactly like
-    ``Frequencies.frequency`` in the reference (prob_dist.py:207-208)."""
+    """Map a block's symbols to alphabet indices (uint8, or uint16 for alphabets above 256 symbols); an unknown symbol
+    raises ``KeyError`` exactly like ``Frequencies.frequency`` in the reference (prob_dist.py:207-208)."""
     data = data_block.data_list
     if isinstance(data, np.ndarray):
         data = data.tolist()
-    return np.fromiter((index_of[s] for s in data), dtype=np.uint8, count=len(data))
+    return np.fromiter((index_of[s] for s in data), dtype=index_dtype(len(index_of)), count=len(data))
 
 
 def indices_to_block(idx: np.ndarray, alphabet: list) -> DataBlock:
@@ -25,6 +30,6 @@ def bitarray_to_packed(bits: BitArray):
 
 
 def check_alphabet(alphabet):
-    if len(alphabet) > 256:
+    if len(alphabet) > 65536:
         raise NotImplementedError(
-            f"alphabet of {len(alphabet)} symbols: the MI355X kernels carry symbols as uint8 indices (<= 256)")
+            f"alphabet of {len(alphabet)} symbols: the MI355X kernels carry symbols as uint8 / uint16 indices (<= 65536)")

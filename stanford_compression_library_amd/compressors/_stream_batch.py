@@ -55,11 +55,11 @@ class BatchedStreamEncoderMixin:
         model, index_of = self._batch_model()
         n = len(blocks)
         width = (block_size + 15) // 16 * 16
-        sym = np.zeros((n, width), dtype=np.uint8)
+        sym = np.zeros((n, width), dtype=model.sym_dtype)  # uint8, or uint16 for alphabets above 256 symbols
         lens = np.zeros(n, dtype=np.int32)
         for i, blk in enumerate(blocks):
             data = blk.data_list
-            sym[i, :len(data)] = np.fromiter((index_of[s] for s in data), dtype=np.uint8, count=len(data))
+            sym[i, :len(data)] = np.fromiter((index_of[s] for s in data), dtype=model.sym_dtype, count=len(data))
             lens[i] = len(data)
         dev = torch.device("cuda", torch.cuda.current_device())
         enc = model.encode_batch(torch.from_numpy(sym).to(dev)[:, :block_size] if width == block_size

@@ -270,25 +270,32 @@ __device__ __forceinline__ u64 aec_cmax(u128 state, u128 low, u64 T, u128 rng) {
     return q;
 }
 
-template <bool LDS16, bool WIDE = false>
-__global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__restrict__ sym, u64 sym_stride,
+// SYM = u8: alphabets up to 256 (static tables staged in LDS).  SYM = u16 (the *_u16 entry points): alphabets up to 65536,
+// static tables read where they are in device memory, adaptive rows scanned linearly; strides count SYMBOLS in both.
+template <bool LDS16, bool WIDE = false, typename SYM = u8>
+__global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const SYM *__restrict__ sym, u64 sym_stride,
                                                         const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                         u8 *__restrict__ out, u64 out_stride,
                                                         u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
                                                         u32 *__restrict__ status, u32 *__restrict__ scratch,
                                                         u64 *__restrict__ ctx_state) {
-    __shared__ u32 s_f[256];
-    __shared__ u32 s_c[256];
+    __shared__ u32 s_f_lds[sizeof(SYM) == 1 ? 256 : 1];
+    __shared__ u32 s_c_lds[sizeof(SYM) == 1 ? 256 : 1];
     __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
-    if (P.kind == SCL_MODEL_FIXED) {
-        scl_load_table(s_f, P.d_freq, P.K);
-        scl_load_table(s_c, P.d_cum, P.K);
+    const u32 *s_f = P.d_freq, *s_c = P.d_cum;
+    if constexpr (sizeof(SYM) == 1) {
+        if (P.kind == SCL_MODEL_FIXED) {
+            scl_load_table(s_f_lds, P.d_freq, P.K);
+            scl_load_table(s_c_lds, P.d_cum, P.K);
+        }
+        __syncthreads();
+        s_f = s_f_lds;
+        s_c = s_c_lds;
     }
-    __syncthreads();
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
-    const u8 *src = sym + c * sym_stride;
+    const SYM *src = sym + c * sym_stride;
     typedef typename AecWord<WIDE>::T W;
     const W FULL = (W)1 << P.P, HALF = FULL >> 1, QTR = FULL >> 2;
     LaneModel<LDS16> mdl;
@@ -353,22 +360,27 @@ __global__ void __launch_bounds__(256) aec_encode_kernel(AecDev P, const u8 *__r
     if (status) status[c] = st;
 }
 
-template <bool LDS16, bool WIDE = false>
+template <bool LDS16, bool WIDE = false, typename SYM = u8>
 __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                                                         const u64 *__restrict__ bit_off,
                                                         const u32 *__restrict__ in_nbits, u64 n_chunks,
-                                                        u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
+                                                        SYM *__restrict__ out_sym, u64 out_stride, u32 out_cap,
                                                         u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
                                                         u32 *__restrict__ status, u32 *__restrict__ scratch,
                                                         u64 *__restrict__ ctx_state) {
-    __shared__ u32 s_f[256];
-    __shared__ u32 s_c[256];
+    __shared__ u32 s_f_lds[sizeof(SYM) == 1 ? 256 : 1];
+    __shared__ u32 s_c_lds[sizeof(SYM) == 1 ? 256 : 1];
     __shared__ u16 s_cnt[LDS16 ? AEC_LDS_CELLS * 256 : 2];
-    if (P.kind == SCL_MODEL_FIXED) {
-        scl_load_table(s_f, P.d_freq, P.K);
-        scl_load_table(s_c, P.d_cum, P.K);
+    const u32 *s_f = P.d_freq, *s_c = P.d_cum;
+    if constexpr (sizeof(SYM) == 1) {
+        if (P.kind == SCL_MODEL_FIXED) {
+            scl_load_table(s_f_lds, P.d_freq, P.K);
+            scl_load_table(s_c_lds, P.d_cum, P.K);
+        }
+        __syncthreads();
+        s_f = s_f_lds;
+        s_c = s_c_lds;
     }
-    __syncthreads();
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     typedef typename AecWord<WIDE>::T W;
@@ -393,7 +405,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
     }
     LaneModel<LDS16> mdl;
     mdl.init(&P, scratch, c, s_cnt + threadIdx.x, ctx_state);
-    u8 *dst = out_sym + c * out_stride;
+    SYM *dst = out_sym + c * out_stride;
     // bit positions relative to the first bit after the header; bits past the end read as 0 (:258-261)
     const u64 body = r.pos;
     u64 used = P.P;  // the state register is always filled with PRECISION bits (:222-229)
@@ -412,7 +424,7 @@ __global__ void __launch_bounds__(256) aec_decode_kernel(AecDev P, const u8 *__r
         const u32 s = mdl.search(cmax, s_f, s_c, cs, fs);
         high = low + aec_muldiv(rng, cs + fs, T);
         low = low + aec_muldiv(rng, cs, T);
-        dst[ndec++] = (u8)s;
+        dst[ndec++] = (SYM)s;
         mdl.update(s, fs);
         if (ndec == n) break;  // before the renormalisation, :242-243
         while (high < HALF || low > HALF) {
@@ -456,7 +468,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     *out = nullptr;
     SCL_REQUIRE(model_kind == SCL_MODEL_FIXED || model_kind == SCL_MODEL_IID || model_kind == SCL_MODEL_ORDERK,
                 "aec_model_create: unknown model kind %d", model_kind);
-    SCL_REQUIRE(K >= 1 && K <= 256, "aec_model_create: alphabet size %u outside 1..256", K);
+    SCL_REQUIRE(K >= 1 && K <= SCL_MAX_ALPHABET, "aec_model_create: alphabet size %u outside 1..65536", K);
     SCL_REQUIRE(precision >= 8 && precision <= 62, "aec_model_create: PRECISION %u outside 8..62", precision);
     SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "aec_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32", size_bits);
     SCL_REQUIRE(max_total >= 2, "aec_model_create: max_allowed_total_freq too small");
@@ -472,7 +484,8 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
     m->dev.cells = 0;
     m->dev.fenwick = 0;
     m->dev.row_cells = 0;
-    u32 freq[256], cum[256];
+    std::vector<u32> freq_v(K), cum_v(K);
+    u32 *freq = freq_v.data(), *cum = cum_v.data();
     u64 tot = 0;
     if (model_kind == SCL_MODEL_ORDERK) {
         if (order_k > 3) {
@@ -492,7 +505,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
             return SCL_E_PARAM;
         }
         m->dev.cells = cells;
-        if (K >= 32 && cells > AEC_LDS_CELLS) {  // two-level rows: 16 block totals + counts in blocks of 16
+        if (K >= 32 && K <= 256 && cells > AEC_LDS_CELLS) {  // two-level rows: 16 block totals + counts in blocks of 16
             m->dev.fenwick = 1;
             m->dev.row_cells = 16 + 16 * ((K + 15) / 16);
             m->dev.cells = m->dev.ctx_mod * m->dev.row_cells;
@@ -521,12 +534,13 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
         m->dev.cells = (model_kind == SCL_MODEL_IID) ? K : 0;
     }
     m->dev.total0 = (u32)tot;
-    ::memcpy(m->h_freq, freq, K * sizeof(u32));
-    hipError_t e = hipMalloc((void **)&m->d_freq, 256 * sizeof(u32));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
+    ::memcpy(m->h_freq, freq, (K < 256 ? K : 256) * sizeof(u32));
+    const u64 tab_entries = K > 256 ? K : 256;
+    hipError_t e = hipMalloc((void **)&m->d_freq, tab_entries * sizeof(u32));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, tab_entries * sizeof(u32));
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
-    if (e == hipSuccess && model_kind == SCL_MODEL_IID && K > 16) {
+    if (e == hipSuccess && model_kind == SCL_MODEL_IID && K > 16 && K <= 256) {
         u32 init[136];
         aec_iid_build_init(freq, K, init);
         e = hipMalloc((void **)&m->d_iid_init, sizeof(init));
@@ -591,6 +605,7 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
                                     uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
                                     uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes, void *stream) {
     SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "aec_encode_batch: null pointer argument");
+    SCL_REQUIRE(m->dev.K <= 256, "aec_encode_batch: alphabet of %u symbols: use scl_aec_encode_batch_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "aec_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
                 "aec_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
@@ -674,6 +689,7 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
                                     void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "aec_decode_batch: null pointer argument");
+    SCL_REQUIRE(m->dev.K <= 256, "aec_decode_batch: alphabet of %u symbols: use scl_aec_decode_batch_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "aec_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
@@ -878,6 +894,7 @@ extern "C" int scl_aec_encode_batch_resume(const scl_aec_model *m, const uint8_t
                                            uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
                                            uint64_t state_bytes, uint64_t n_coders, void *stream) {
     SCL_REQUIRE(m, "aec_encode_batch_resume: null model");
+    SCL_REQUIRE(m->dev.K <= 256, "aec_encode_batch_resume: alphabet of %u symbols: use scl_aec_encode_batch_resume_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "aec_encode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)  // nothing to carry
         return scl_aec_encode_batch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
@@ -916,6 +933,7 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
                                            uint32_t *d_out_lens, uint32_t *d_consumed, uint32_t *d_status,
                                            void *d_state, uint64_t state_bytes, uint64_t n_coders, void *stream) {
     SCL_REQUIRE(m, "aec_decode_batch_resume: null model");
+    SCL_REQUIRE(m->dev.K <= 256, "aec_decode_batch_resume: alphabet of %u symbols: use scl_aec_decode_batch_resume_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "aec_decode_batch_resume")) return rc_dev;
     if (m->dev.kind == SCL_MODEL_FIXED)
         return scl_aec_decode_batch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
@@ -944,6 +962,124 @@ extern "C" int scl_aec_decode_batch_resume(const scl_aec_model *m, const uint8_t
     } while (0);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
+}
+
+
+// ---- uint16 symbol indices: alphabets up to 65536 (any model; the any-parameter kernels, counts in device memory) ----
+// d_state != nullptr: the *_resume form (chunk c continues coder c of a state reset with n_coders coders)
+static int aec_encode_u16(const char *what, const scl_aec_model *m, const u16 *d_sym, u64 sym_stride, const u32 *d_lens,
+                          u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset,
+                          u32 *d_out_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes, void *d_state,
+                          u64 state_bytes, u64 n_coders, hipStream_t st) {
+    SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "%s: null pointer argument", what);
+    if (int rc_dev = scl_check_device(m->device, what)) return rc_dev;
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32), "%s: bad out_stride %llu", what,
+                (unsigned long long)out_stride);
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_sym & 1) == 0,
+                "%s: d_out must be 16-byte aligned, d_sym 2-byte aligned", what);
+    u32 *cells = (u32 *)d_scratch;
+    u64 *ctx_state = nullptr;
+    if (d_state && m->dev.kind != SCL_MODEL_FIXED) {
+        SCL_REQUIRE(((uintptr_t)d_state & 255) == 0, "%s: d_state must be 256-byte aligned", what);
+        SCL_REQUIRE(n_chunks <= n_coders, "%s: %llu chunks but the state holds %llu coders", what,
+                    (unsigned long long)n_chunks, (unsigned long long)n_coders);
+        SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_coders), "%s: state of %llu bytes required", what,
+                    (unsigned long long)scl_aec_state_bytes(m, n_coders));
+        cells = (u32 *)d_state;
+        ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
+    }
+    if (n_chunks == 0) return SCL_OK;
+    if (!ctx_state)
+        if (int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st)) return rc;
+    const dim3 grid((u32)((n_chunks + 255) / 256)), block(256);
+    if (m->dev.P > 32)
+        hipLaunchKernelGGL((aec_encode_kernel<false, true, u16>), grid, block, 0, st, m->dev, d_sym, sym_stride, d_lens,
+                           chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status, cells,
+                           ctx_state);
+    else
+        hipLaunchKernelGGL((aec_encode_kernel<false, false, u16>), grid, block, 0, st, m->dev, d_sym, sym_stride, d_lens,
+                           chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status, cells,
+                           ctx_state);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+static int aec_decode_u16(const char *what, const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes,
+                          const u64 *d_bit_offset, const u32 *d_in_nbits, u64 n_chunks, u16 *d_out_sym, u64 out_stride,
+                          u32 out_cap, u32 *d_out_lens, u32 *d_consumed, u32 *d_status, void *d_scratch,
+                          u64 scratch_bytes, void *d_state, u64 state_bytes, u64 n_coders, hipStream_t st) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "%s: null pointer argument", what);
+    if (int rc_dev = scl_check_device(m->device, what)) return rc_dev;
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0 && ((uintptr_t)d_out_sym & 1) == 0,
+                "%s: d_in must be 4-byte aligned, d_out_sym 2-byte aligned", what);
+    u32 *cells = (u32 *)d_scratch;
+    u64 *ctx_state = nullptr;
+    if (d_state && m->dev.kind != SCL_MODEL_FIXED) {
+        SCL_REQUIRE(((uintptr_t)d_state & 255) == 0, "%s: d_state must be 256-byte aligned", what);
+        SCL_REQUIRE(n_chunks <= n_coders, "%s: %llu chunks but the state holds %llu coders", what,
+                    (unsigned long long)n_chunks, (unsigned long long)n_coders);
+        SCL_REQUIRE(state_bytes >= scl_aec_state_bytes(m, n_coders), "%s: state of %llu bytes required", what,
+                    (unsigned long long)scl_aec_state_bytes(m, n_coders));
+        cells = (u32 *)d_state;
+        ctx_state = (u64 *)((u8 *)d_state + aec_state_cells_bytes(m, n_coders));
+    }
+    if (n_chunks == 0) return SCL_OK;
+    if (!ctx_state)
+        if (int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st)) return rc;
+    const dim3 grid((u32)((n_chunks + 255) / 256)), block(256);
+    if (m->dev.P > 32)
+        hipLaunchKernelGGL((aec_decode_kernel<false, true, u16>), grid, block, 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                           d_status, cells, ctx_state);
+    else
+        hipLaunchKernelGGL((aec_decode_kernel<false, false, u16>), grid, block, 0, st, m->dev, d_in, in_size_bytes,
+                           d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
+                           d_status, cells, ctx_state);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_aec_encode_batch_u16(const scl_aec_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                                        const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks, uint8_t *d_out,
+                                        uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
+                                        uint32_t *d_status, void *d_scratch, uint64_t scratch_bytes, void *stream) {
+    return aec_encode_u16("aec_encode_batch_u16", m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                          d_out_bit_offset, d_out_nbits, d_status, d_scratch, scratch_bytes, nullptr, 0, 0,
+                          (hipStream_t)stream);
+}
+
+extern "C" int scl_aec_decode_batch_u16(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                        const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
+                                        uint16_t *d_out_sym, uint64_t out_stride, uint32_t out_cap,
+                                        uint32_t *d_out_lens, uint32_t *d_consumed, uint32_t *d_status, void *d_scratch,
+                                        uint64_t scratch_bytes, void *stream) {
+    return aec_decode_u16("aec_decode_batch_u16", m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym,
+                          out_stride, out_cap, d_out_lens, d_consumed, d_status, d_scratch, scratch_bytes, nullptr, 0, 0,
+                          (hipStream_t)stream);
+}
+
+extern "C" int scl_aec_encode_batch_resume_u16(const scl_aec_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                                               const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                               uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                               uint32_t *d_out_nbits, uint32_t *d_status, void *d_state,
+                                               uint64_t state_bytes, uint64_t n_coders, void *stream) {
+    SCL_REQUIRE(m && (d_state || m->dev.kind == SCL_MODEL_FIXED), "aec_encode_batch_resume_u16: null model or state");
+    return aec_encode_u16("aec_encode_batch_resume_u16", m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out,
+                          out_stride, d_out_bit_offset, d_out_nbits, d_status, nullptr, 0, d_state, state_bytes, n_coders,
+                          (hipStream_t)stream);
+}
+
+extern "C" int scl_aec_decode_batch_resume_u16(const scl_aec_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                               const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                               uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                                               uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                               uint32_t *d_status, void *d_state, uint64_t state_bytes,
+                                               uint64_t n_coders, void *stream) {
+    SCL_REQUIRE(m && (d_state || m->dev.kind == SCL_MODEL_FIXED), "aec_decode_batch_resume_u16: null model or state");
+    return aec_decode_u16("aec_decode_batch_resume_u16", m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks,
+                          d_out_sym, out_stride, out_cap, d_out_lens, d_consumed, d_status, nullptr, 0, d_state,
+                          state_bytes, n_coders, (hipStream_t)stream);
 }
 
 // ---- single-chunk host drivers --------------------------------------------------------------------------
@@ -1021,4 +1157,70 @@ extern "C" int scl_aec_decode_host_resume(const scl_aec_model *m, const uint8_t 
     AecHostState hs = {h_counts, h_past_k};
     HostDecodeCall call = {aec_run_dec_resume, aec_state1, aec_state_pre, aec_state_post, &hs};
     return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}
+
+// ---- single-chunk host drivers, uint16 symbol indices --------------------------------------------------------
+static int aec_run_enc16(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                         u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_encode_batch_u16((const scl_aec_model *)model, (const u16 *)d_sym, n, nullptr, n, 1, d_out, out_stride,
+                                    d_bit_off, d_nbits, d_status, d_scratch, scratch_bytes, nullptr);
+}
+static int aec_run_dec16(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
+                         u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *d_scratch,
+                         u64 scratch_bytes) {
+    return scl_aec_decode_batch_u16((const scl_aec_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
+                                    (u16 *)d_out_sym, (u64)out_cap + 1, out_cap, d_out_len, d_consumed, d_status,
+                                    d_scratch, scratch_bytes, nullptr);
+}
+static int aec_run_enc_resume16(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                                u32 *d_nbits, u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_encode_batch_resume_u16((const scl_aec_model *)model, (const u16 *)d_sym, n, nullptr, n, 1, d_out,
+                                           out_stride, d_bit_off, d_nbits, d_status, d_scratch, scratch_bytes, 1,
+                                           nullptr);
+}
+static int aec_run_dec_resume16(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off,
+                                const u32 *d_in_nbits, u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed,
+                                u32 *d_status, void *d_scratch, u64 scratch_bytes) {
+    return scl_aec_decode_batch_resume_u16((const scl_aec_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
+                                           (u16 *)d_out_sym, (u64)out_cap + 1, out_cap, d_out_len, d_consumed, d_status,
+                                           d_scratch, scratch_bytes, 1, nullptr);
+}
+
+extern "C" int scl_aec_encode_host_u16(const scl_aec_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                                       uint64_t out_cap_bytes, uint64_t *nbits) {
+    HostEncodeCall call = {aec_run_enc16, aec_slot, aec_scratch};
+    call.sym_bytes = 2;
+    return scl_host_encode_one(call, m, (const u8 *)h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_aec_decode_host_u16(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                       uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
+    HostDecodeCall call = {aec_run_dec16, aec_scratch};
+    call.sym_bytes = 2;
+    return scl_host_decode_one(call, m, h_in, in_nbits, (u8 *)h_out_sym, out_cap, n_out, consumed);
+}
+
+extern "C" int scl_aec_encode_host_resume_u16(const scl_aec_model *m, const uint16_t *h_sym, uint64_t n,
+                                              uint8_t *h_out, uint64_t out_cap_bytes, uint64_t *nbits,
+                                              uint32_t *h_counts, uint32_t *h_past_k) {
+    SCL_REQUIRE(m, "aec_encode_host_resume_u16: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED) return scl_aec_encode_host_u16(m, h_sym, n, h_out, out_cap_bytes, nbits);
+    SCL_REQUIRE(h_counts && (m->dev.k == 0 || h_past_k), "aec_encode_host_resume_u16: null state arrays");
+    AecHostState hs = {h_counts, h_past_k};
+    HostEncodeCall call = {aec_run_enc_resume16, aec_slot, aec_state1, aec_state_pre, aec_state_post, &hs};
+    call.sym_bytes = 2;
+    return scl_host_encode_one(call, m, (const u8 *)h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_aec_decode_host_resume_u16(const scl_aec_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                              uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out,
+                                              uint64_t *consumed, uint32_t *h_counts, uint32_t *h_past_k) {
+    SCL_REQUIRE(m, "aec_decode_host_resume_u16: null model");
+    if (m->dev.kind == SCL_MODEL_FIXED)
+        return scl_aec_decode_host_u16(m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+    SCL_REQUIRE(h_counts && (m->dev.k == 0 || h_past_k), "aec_decode_host_resume_u16: null state arrays");
+    AecHostState hs = {h_counts, h_past_k};
+    HostDecodeCall call = {aec_run_dec_resume16, aec_state1, aec_state_pre, aec_state_post, &hs};
+    call.sym_bytes = 2;
+    return scl_host_decode_one(call, m, h_in, in_nbits, (u8 *)h_out_sym, out_cap, n_out, consumed);
 }

@@ -15,7 +15,8 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 #define SCL_WAVE 64
-#define SCL_ABI_VERSION 3
+#define SCL_ABI_VERSION 4
+#define SCL_MAX_ALPHABET 65536u  // uint16 symbol indices (the *_u16 entry points); the uint8 entry points stop at 256
 
 // ---- host-side error plumbing ------------------------------------------------------------------
 void scl_set_error(const char *fmt, ...);
@@ -106,6 +107,7 @@ struct HostEncodeCall {
     int (*pre)(const void *model, void *d_scratch, void *user) = nullptr;
     int (*post)(const void *model, const void *d_scratch, void *user) = nullptr;
     void *user = nullptr;
+    u32 sym_bytes = 1;  // 2: h_sym / d_sym hold uint16 indices (run() forwards to the *_u16 batch entry point)
 };
 struct HostDecodeCall {
     int (*run)(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
@@ -115,6 +117,7 @@ struct HostDecodeCall {
     int (*pre)(const void *model, void *d_scratch, void *user) = nullptr;
     int (*post)(const void *model, const void *d_scratch, void *user) = nullptr;
     void *user = nullptr;
+    u32 sym_bytes = 1;
 };
 int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 *h_sym, u64 n, u8 *h_out,
                         u64 out_cap_bytes, u64 *nbits);

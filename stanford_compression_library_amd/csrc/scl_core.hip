@@ -413,7 +413,7 @@ int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 
     const u64 scratch_bytes = call.scratch_bytes ? call.scratch_bytes(model) : 0;
     ScratchDev d_sym, d_slot, d_meta, d_dense, d_scr, d_cscr;
     int rc;
-    if ((rc = d_sym.alloc(n + 16)) || (rc = d_slot.alloc(slot)) || (rc = d_meta.alloc(64)) ||
+    if ((rc = d_sym.alloc(n * call.sym_bytes + 16)) || (rc = d_slot.alloc(slot)) || (rc = d_meta.alloc(64)) ||
         (rc = d_dense.alloc(slot + 16)) || (rc = d_scr.alloc(scratch_bytes)) ||
         (rc = d_cscr.alloc(scl_streams_compact_scratch_bytes(1))))
         return rc;
@@ -421,7 +421,7 @@ int scl_host_encode_one(const HostEncodeCall &call, const void *model, const u8 
     u64 *d_rec_off = (u64 *)d_meta.p + 1;       // [1..2]
     u32 *d_nbits = (u32 *)((u64 *)d_meta.p + 4);  // byte 32
     u32 *d_status = d_nbits + 1;
-    if (n) SCL_HIP_TRY(hipMemcpy(d_sym.p, h_sym, n, hipMemcpyHostToDevice));
+    if (n) SCL_HIP_TRY(hipMemcpy(d_sym.p, h_sym, n * call.sym_bytes, hipMemcpyHostToDevice));
     SCL_HIP_TRY(hipMemset(d_meta.p, 0, 64));
     if (call.pre && (rc = call.pre(model, d_scr.p, call.user))) return rc;
     rc = call.run(model, (const u8 *)d_sym.p, (u32)n, (u8 *)d_slot.p, slot, d_bit_off, d_nbits, d_status, d_scr.p,
@@ -454,7 +454,7 @@ int scl_host_decode_one(const HostDecodeCall &call, const void *model, const u8 
     const u64 scratch_bytes = call.scratch_bytes ? call.scratch_bytes(model) : 0;
     ScratchDev d_in, d_out, d_meta, d_scr;
     int rc;
-    if ((rc = d_in.alloc(in_bytes + 32)) || (rc = d_out.alloc(out_cap + 16)) || (rc = d_meta.alloc(64)) ||
+    if ((rc = d_in.alloc(in_bytes + 32)) || (rc = d_out.alloc((out_cap + 16) * call.sym_bytes)) || (rc = d_meta.alloc(64)) ||
         (rc = d_scr.alloc(scratch_bytes)))
         return rc;
     SCL_HIP_TRY(hipMemset(d_in.p, 0, in_bytes + 32));
@@ -477,7 +477,7 @@ int scl_host_decode_one(const HostDecodeCall &call, const void *model, const u8 
     *n_out = meta[0];
     *consumed = meta[1];
     if ((rc = status_to_error(meta[2], "decode_host"))) return rc;
-    if (meta[0]) SCL_HIP_TRY(hipMemcpy(h_out_sym, d_out.p, meta[0], hipMemcpyDeviceToHost));
+    if (meta[0]) SCL_HIP_TRY(hipMemcpy(h_out_sym, d_out.p, (u64)meta[0] * call.sym_bytes, hipMemcpyDeviceToHost));
     if (call.post && (rc = call.post(model, d_scr.p, call.user))) return rc;
     return SCL_OK;
 }

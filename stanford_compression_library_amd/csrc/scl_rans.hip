@@ -18,6 +18,8 @@
 //                (scl_rans_fast_b.hip): same I/O, division in binary64.
 #include <string.h>
 
+#include <vector>
+
 #include "scl_common.h"
 
 #include "scl_rans_internal.h"
@@ -25,21 +27,28 @@
 // =====================================================================================================
 // generic kernels
 // =====================================================================================================
-template <typename ST>
-__global__ void __launch_bounds__(256) rans_encode_generic(RansDev P, const u8 *__restrict__ sym, u64 sym_stride,
+// SYM = u8: alphabets up to 256, tables staged in LDS.  SYM = u16 (the *_u16 entry points): alphabets up to 65536,
+// tables read where they are (d_freq / d_cum in device memory, L2-resident); strides count SYMBOLS in both.
+template <typename ST, typename SYM = u8>
+__global__ void __launch_bounds__(256) rans_encode_generic(RansDev P, const SYM *__restrict__ sym, u64 sym_stride,
                                                           const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                           u8 *__restrict__ out, u64 out_stride,
                                                           u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
                                                           u32 *__restrict__ status) {
-    __shared__ u32 s_f[256];
-    __shared__ u32 s_c[256];
-    scl_load_table(s_f, P.d_freq, P.K);
-    scl_load_table(s_c, P.d_cum, P.K);
-    __syncthreads();
+    __shared__ u32 s_f_lds[sizeof(SYM) == 1 ? 256 : 1];
+    __shared__ u32 s_c_lds[sizeof(SYM) == 1 ? 256 : 1];
+    const u32 *s_f = P.d_freq, *s_c = P.d_cum;
+    if constexpr (sizeof(SYM) == 1) {
+        scl_load_table(s_f_lds, P.d_freq, P.K);
+        scl_load_table(s_c_lds, P.d_cum, P.K);
+        __syncthreads();
+        s_f = s_f_lds;
+        s_c = s_c_lds;
+    }
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
-    const u8 *src = sym + c * sym_stride;
+    const SYM *src = sym + c * sym_stride;
     BackBitWriter w;
     w.init(out + c * out_stride, out_stride);
     u32 st = 0;
@@ -78,18 +87,23 @@ __global__ void __launch_bounds__(256) rans_encode_generic(RansDev P, const u8 *
     if (status) status[c] = st;
 }
 
-template <typename ST>
+template <typename ST, typename SYM = u8>
 __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                                                           const u64 *__restrict__ bit_off,
                                                           const u32 *__restrict__ in_nbits, u64 n_chunks,
-                                                          u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
+                                                          SYM *__restrict__ out_sym, u64 out_stride, u32 out_cap,
                                                           u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
                                                           u32 *__restrict__ status) {
-    __shared__ u32 s_f[256];
-    __shared__ u32 s_c[256];
-    scl_load_table(s_f, P.d_freq, P.K);
-    scl_load_table(s_c, P.d_cum, P.K);
-    __syncthreads();
+    __shared__ u32 s_f_lds[sizeof(SYM) == 1 ? 256 : 1];
+    __shared__ u32 s_c_lds[sizeof(SYM) == 1 ? 256 : 1];
+    const u32 *s_f = P.d_freq, *s_c = P.d_cum;
+    if constexpr (sizeof(SYM) == 1) {
+        scl_load_table(s_f_lds, P.d_freq, P.K);
+        scl_load_table(s_c_lds, P.d_cum, P.K);
+        __syncthreads();
+        s_f = s_f_lds;
+        s_c = s_c_lds;
+    }
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     BitReader r;
@@ -107,7 +121,7 @@ __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *
         st |= SCL_ST_CAPACITY;
         n = 0;
     }
-    u8 *dst = out_sym + c * out_stride;
+    SYM *dst = out_sym + c * out_stride;
     const u32 b = P.b;
     const ST M = (ST)P.M, L = (ST)P.L;
     const u32 st_header = st;
@@ -133,7 +147,7 @@ __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *
         x = block_id * (ST)s_f[lo] + slot - (ST)s_c[lo];
         // expand_state :251-260
         while (x < L && !r.truncated) x = (ST)(x << b) + (ST)r.get(b);
-        dst[i] = (u8)lo;  // decoded last symbol first (:291)
+        dst[i] = (SYM)lo;  // decoded last symbol first (:291)
         if (r.truncated) break;
     }
     if (r.truncated) st |= SCL_ST_TRUNCATED;
@@ -148,13 +162,14 @@ __global__ void __launch_bounds__(256) rans_decode_generic(RansDev P, const u8 *
 static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bits, scl_rans_model **out) {
     SCL_REQUIRE(out, "rans_model_create: null output");
     *out = nullptr;
-    SCL_REQUIRE(h_freq && K >= 1 && K <= 256, "rans_model_create: alphabet size %u outside 1..256", K);
+    SCL_REQUIRE(h_freq && K >= 1 && K <= SCL_MAX_ALPHABET, "rans_model_create: alphabet size %u outside 1..65536", K);
     SCL_REQUIRE(b >= 1 && b <= 32, "rans_model_create: NUM_BITS_OUT %u outside 1..32", b);
     SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "rans_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32",
                 size_bits);
     SCL_REQUIRE(RF >= 1, "rans_model_create: RANGE_FACTOR must be >= 1");
     unsigned __int128 M = 0;
-    u32 cum[256];
+    std::vector<u32> cum_v(K);
+    u32 *cum = cum_v.data();
     u32 fmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < K; ++i) {
         SCL_REQUIRE(h_freq[i] > 0, "rans_model_create: zero frequency for symbol %u (division by zero, rANS.py:143)", i);
@@ -190,8 +205,9 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
         }
         m->max_bits_per_symbol = kb;
     }
-    hipError_t e = hipMalloc((void **)&m->d_freq, 256 * sizeof(u32));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, 256 * sizeof(u32));
+    const u64 tab_entries = K > 256 ? K : 256;
+    hipError_t e = hipMalloc((void **)&m->d_freq, tab_entries * sizeof(u32));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_cum, tab_entries * sizeof(u32));
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, h_freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -201,8 +217,9 @@ static int rans_model_build(const u32 *h_freq, u32 K, u64 RF, u32 b, u32 size_bi
     }
     m->dev.d_freq = m->d_freq;
     m->dev.d_cum = m->d_cum;
-    int rc = rans_fast_build_tables(m, h_freq, cum);
-    if (rc == SCL_OK && !m->fast) rc = rans_fastb_build_tables(m, h_freq, cum);
+    // the tuned kernels carry symbols as bytes: alphabets above 256 run the any-parameter kernels (*_u16 entry points)
+    int rc = K <= 256 ? rans_fast_build_tables(m, h_freq, cum) : SCL_OK;
+    if (rc == SCL_OK && !m->fast && K <= 256) rc = rans_fastb_build_tables(m, h_freq, cum);
     if (rc != SCL_OK) {
         scl_rans_model_destroy(m);
         return rc;
@@ -263,6 +280,7 @@ extern "C" int scl_rans_encode_batch(const scl_rans_model *m, const uint8_t *d_s
                                      uint32_t *d_status, void *stream) {
     int rc = check_batch_args("rans_encode_batch", m, d_sym, d_out, d_out_bit_offset, d_out_nbits, out_stride);
     if (rc) return rc;
+    SCL_REQUIRE(m->dev.K <= 256, "rans_encode_batch: alphabet of %u symbols: use scl_rans_encode_batch_u16", m->dev.K);
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "rans_encode_batch: d_out must be 16-byte aligned");
     if (int rc_dev = scl_check_device(m->device, "rans_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride * 8 < (1ull << 32), "rans_encode_batch: slot larger than 512 MiB");
@@ -299,6 +317,7 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
                                      uint32_t *d_consumed, uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "rans_decode_batch: null pointer argument");
+    SCL_REQUIRE(m->dev.K <= 256, "rans_decode_batch: alphabet of %u symbols: use scl_rans_decode_batch_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "rans_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "rans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
@@ -327,6 +346,59 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
     return relay.out_end();
 }
 
+// ---- uint16 symbol indices: alphabets up to 65536 (any model; the any-parameter kernels) -------------------
+extern "C" int scl_rans_encode_batch_u16(const scl_rans_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                                         const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                         uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                         uint32_t *d_out_nbits, uint32_t *d_status, void *stream) {
+    int rc = check_batch_args("rans_encode_batch_u16", m, d_sym, d_out, d_out_bit_offset, d_out_nbits, out_stride);
+    if (rc) return rc;
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_sym & 1) == 0,
+                "rans_encode_batch_u16: d_out must be 16-byte aligned, d_sym 2-byte aligned");
+    if (int rc_dev = scl_check_device(m->device, "rans_encode_batch_u16")) return rc_dev;
+    SCL_REQUIRE(out_stride * 8 < (1ull << 32), "rans_encode_batch_u16: slot larger than 512 MiB");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    if (m->state32)
+        hipLaunchKernelGGL((rans_encode_generic<u32, u16>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
+                           d_status);
+    else
+        hipLaunchKernelGGL((rans_encode_generic<u64, u16>), dim3(blocks), dim3(threads), 0, st, m->dev, d_sym,
+                           sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
+                           d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_rans_decode_batch_u16(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                         const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                         uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                                         uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                         uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "rans_decode_batch_u16: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "rans_decode_batch_u16")) return rc_dev;
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0 && ((uintptr_t)d_out_sym & 1) == 0,
+                "rans_decode_batch_u16: d_in must be 4-byte aligned, d_out_sym 2-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    if (m->state32)
+        hipLaunchKernelGGL((rans_decode_generic<u32, u16>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in,
+                           in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                           d_out_lens, d_consumed, d_status);
+    else
+        hipLaunchKernelGGL((rans_decode_generic<u64, u16>), dim3(blocks), dim3(threads), 0, st, m->dev, d_in,
+                           in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                           d_out_lens, d_consumed, d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
 // ---- single-chunk host drivers ------------------------------------------------------------------------
 static int rans_run_enc(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
                         u32 *d_nbits, u32 *d_status, void *, u64) {
@@ -350,4 +422,30 @@ extern "C" int scl_rans_decode_host(const scl_rans_model *m, const uint8_t *h_in
                                     uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
     HostDecodeCall call = {rans_run_dec, nullptr};
     return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}
+
+static int rans_run_enc16(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                          u32 *d_nbits, u32 *d_status, void *, u64) {
+    return scl_rans_encode_batch_u16((const scl_rans_model *)model, (const u16 *)d_sym, n, nullptr, n, 1, d_out,
+                                     out_stride, d_bit_off, d_nbits, d_status, nullptr);
+}
+static int rans_run_dec16(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
+                          u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *, u64) {
+    return scl_rans_decode_batch_u16((const scl_rans_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
+                                     (u16 *)d_out_sym, (u64)out_cap + 1, out_cap, d_out_len, d_consumed, d_status,
+                                     nullptr);
+}
+
+extern "C" int scl_rans_encode_host_u16(const scl_rans_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                                        uint64_t out_cap_bytes, uint64_t *nbits) {
+    HostEncodeCall call = {rans_run_enc16, rans_slot, nullptr};
+    call.sym_bytes = 2;
+    return scl_host_encode_one(call, m, (const u8 *)h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_rans_decode_host_u16(const scl_rans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                        uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
+    HostDecodeCall call = {rans_run_dec16, nullptr};
+    call.sym_bytes = 2;
+    return scl_host_decode_one(call, m, h_in, in_nbits, (u8 *)h_out_sym, out_cap, n_out, consumed);
 }

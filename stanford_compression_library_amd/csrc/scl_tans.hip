@@ -14,6 +14,8 @@
 // The bit stream is identical to rANS with the same parameters (same layout as scl_rans.hip).
 #include <string.h>
 
+#include <vector>
+
 #include "scl_tans_internal.h"
 #include "scl_rans_internal.h"
 
@@ -61,7 +63,10 @@ __global__ void tans_build_tables(u32 K, u32 M, u32 RF, u32 m_log2, u32 nsb, con
 }
 
 // ---- encode ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tans_encode_kernel(TansDev P, const u8 *__restrict__ sym, u64 sym_stride,
+// SYM = u8: alphabets up to 256, per-symbol tables staged in LDS.  SYM = u16 (the *_u16 entry points): alphabets up to
+// 65536, every table read where it is in device memory; strides count SYMBOLS in both.
+template <typename SYM = u8>
+__global__ void __launch_bounds__(256) tans_encode_kernel(TansDev P, const SYM *__restrict__ sym, u64 sym_stride,
                                                          const u32 *__restrict__ lens, u32 chunk_len, u64 n_chunks,
                                                          u8 *__restrict__ out, u64 out_stride,
                                                          u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits,
@@ -71,18 +76,21 @@ __global__ void __launch_bounds__(256) tans_encode_kernel(TansDev P, const u8 *_
     u32 *s_thresh = s_mem + 256;   // [256]
     int *s_off = (int *)(s_mem + 512);  // [256]  RF*c[s] - RF*f[s]
     u32 *s_enc = s_mem + 768;      // [L] when lds_tables
-    for (u32 i = threadIdx.x; i < P.K; i += blockDim.x) {
-        s_nbits[i] = P.d_nbits[i];
-        s_thresh[i] = P.d_thresh[i];
-        s_off[i] = (int)(P.RF * P.d_cum[i]) - (int)(P.RF * P.d_freq[i]);
+    constexpr bool WIDE_SYM = sizeof(SYM) > 1;
+    if (!WIDE_SYM) {
+        for (u32 i = threadIdx.x; i < P.K; i += blockDim.x) {
+            s_nbits[i] = P.d_nbits[i];
+            s_thresh[i] = P.d_thresh[i];
+            s_off[i] = (int)(P.RF * P.d_cum[i]) - (int)(P.RF * P.d_freq[i]);
+        }
+        if (P.lds_tables) scl_load_table(s_enc, P.d_enc, P.L);
+        __syncthreads();
     }
-    if (P.lds_tables) scl_load_table(s_enc, P.d_enc, P.L);
-    __syncthreads();
-    const u32 *enc = P.lds_tables ? s_enc : P.d_enc;
+    const u32 *enc = (!WIDE_SYM && P.lds_tables) ? s_enc : P.d_enc;
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
-    const u8 *src = sym + c * sym_stride;
+    const SYM *src = sym + c * sym_stride;
     BackBitWriter w;
     w.init(out + c * out_stride, out_stride);
     u32 st = 0;
@@ -94,10 +102,21 @@ __global__ void __launch_bounds__(256) tans_encode_kernel(TansDev P, const u8 *_
             s = 0;
         }
         // encode_symbol, tANS.py:126-157: two table reads, one compare, one shift, one table read
-        const u32 nb = s_nbits[s] + (x >= s_thresh[s] ? 1u : 0u);
+        u32 nb1, thr;
+        int off;
+        if (WIDE_SYM) {
+            nb1 = P.d_nbits[s];
+            thr = P.d_thresh[s];
+            off = (int)(P.RF * P.d_cum[s]) - (int)(P.RF * P.d_freq[s]);
+        } else {
+            nb1 = s_nbits[s];
+            thr = s_thresh[s];
+            off = s_off[s];
+        }
+        const u32 nb = nb1 + (x >= thr ? 1u : 0u);
         if (nb) w.put(x & ((1u << nb) - 1u), nb);
         x >>= nb;
-        x = enc[(u32)(s_off[s] + (int)x)];
+        x = enc[(u32)(off + (int)x)];
     }
     w.put(x, P.nsb);
     if (P.size_bits < 32 && (n >> P.size_bits)) st |= SCL_ST_SIZE;
@@ -110,10 +129,11 @@ __global__ void __launch_bounds__(256) tans_encode_kernel(TansDev P, const u8 *_
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------
+template <typename SYM = u8>
 __global__ void __launch_bounds__(256) tans_decode_kernel(TansDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                                                          const u64 *__restrict__ bit_off,
                                                          const u32 *__restrict__ in_nbits, u64 n_chunks,
-                                                         u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap,
+                                                         SYM *__restrict__ out_sym, u64 out_stride, u32 out_cap,
                                                          u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
                                                          u32 *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[];
@@ -146,7 +166,7 @@ __global__ void __launch_bounds__(256) tans_decode_kernel(TansDev P, const u8 *_
         st |= SCL_ST_CAPACITY;
         n = 0;
     }
-    u8 *dst = out_sym + c * out_stride;
+    SYM *dst = out_sym + c * out_stride;
     const u32 st_header = st;
     for (u32 i = n; i-- > 0;) {
         // decode_symbol, tANS.py:239-250
@@ -155,7 +175,7 @@ __global__ void __launch_bounds__(256) tans_decode_kernel(TansDev P, const u8 *_
         const u32 nb = P.nsb - tans_bit_width(xs);  // expand_state_num_bits_table :217-226
         const u32 rem = nb ? r.get(nb) : 0u;
         x = (xs << nb) + rem;
-        dst[i] = (u8)s;
+        dst[i] = (SYM)s;
         if (r.truncated) break;
     }
     if (r.truncated) st |= SCL_ST_TRUNCATED;
@@ -202,12 +222,13 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
                                      scl_tans_model **out) {
     SCL_REQUIRE(out, "tans_model_create: null output");
     *out = nullptr;
-    SCL_REQUIRE(h_freq && K >= 1 && K <= 256, "tans_model_create: alphabet size %u outside 1..256", K);
+    SCL_REQUIRE(h_freq && K >= 1 && K <= SCL_MAX_ALPHABET, "tans_model_create: alphabet size %u outside 1..65536", K);
     SCL_REQUIRE(size_bits >= 1 && size_bits <= 32, "tans_model_create: DATA_BLOCK_SIZE_BITS %u outside 1..32",
                 size_bits);
     SCL_REQUIRE(range_factor >= 1 && range_factor <= (1ull << 30), "tans_model_create: RANGE_FACTOR outside 1..2^30");
     u64 M = 0;
-    u32 cum[256], fmin = 0xFFFFFFFFu;
+    std::vector<u32> cum_v(K);
+    u32 *cum = cum_v.data(), fmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < K; ++i) {
         SCL_REQUIRE(h_freq[i] > 0, "tans_model_create: zero frequency for symbol %u", i);
         cum[i] = (u32)M;
@@ -257,10 +278,11 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     auto alloc = [&](u32 **p, u64 n) {
         if (e == hipSuccess) e = hipMalloc((void **)p, (n ? n : 1) * sizeof(u32));
     };
-    alloc(&m->d_freq, 256);
-    alloc(&m->d_cum, 256);
-    alloc(&m->d_nbits, 256);
-    alloc(&m->d_thresh, 256);
+    const u64 tab_entries = K > 256 ? K : 256;
+    alloc(&m->d_freq, tab_entries);
+    alloc(&m->d_cum, tab_entries);
+    alloc(&m->d_nbits, tab_entries);
+    alloc(&m->d_thresh, tab_entries);
     if (e == hipSuccess) e = hipMemcpy(m->d_freq, h_freq, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cum, cum, K * sizeof(u32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -277,7 +299,7 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     // 2^26 entries) are only built if somebody asks for them (scl_tans_model_tables, or rows the tuned kernels
     // cannot take) -- tans_ensure_tables.
     int rc = (m->tables && !m->rans) ? tans_ensure_tables(m) : SCL_OK;
-    if (rc == SCL_OK && m->tables && !m->rans) rc = tans_fast_build_tables(m, h_freq, cum);
+    if (rc == SCL_OK && m->tables && !m->rans && K <= 256) rc = tans_fast_build_tables(m, h_freq, cum);
     if (rc != SCL_OK) {
         scl_tans_model_destroy(m);
         return rc;
@@ -339,6 +361,7 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
                                      uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
                                      uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "tans_encode_batch: null pointer argument");
+    SCL_REQUIRE(m->dev.K <= 256, "tans_encode_batch: alphabet of %u symbols: use scl_tans_encode_batch_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "tans_encode_batch")) return rc_dev;
     SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
                 "tans_encode_batch: bad out_stride %llu", (unsigned long long)out_stride);
@@ -369,7 +392,7 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (768 + (m->dev.lds_tables ? m->dev.L : 0)) * sizeof(u32);
-    hipLaunchKernelGGL(tans_encode_kernel, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, m->dev, d_sym,
+    hipLaunchKernelGGL(tans_encode_kernel<u8>, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, m->dev, d_sym,
                        sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
                        d_status);
     SCL_HIP_TRY(hipGetLastError());
@@ -382,6 +405,7 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                                      uint32_t *d_consumed, uint32_t *d_status, void *stream) {
     SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
                 "tans_decode_batch: null pointer argument");
+    SCL_REQUIRE(m->dev.K <= 256, "tans_decode_batch: alphabet of %u symbols: use scl_tans_decode_batch_u16", m->dev.K);
     if (int rc_dev = scl_check_device(m->device, "tans_decode_batch")) return rc_dev;
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "tans_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
@@ -408,11 +432,58 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
     const u32 lds = (m->dev.lds_tables ? 2 * m->dev.L : 4) * sizeof(u32);
-    hipLaunchKernelGGL(tans_decode_kernel, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, m->dev, d_in,
+    hipLaunchKernelGGL(tans_decode_kernel<u8>, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, m->dev, d_in,
                        in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                        d_consumed, d_status);
     SCL_HIP_TRY(hipGetLastError());
     return relay.out_end();
+}
+
+// ---- uint16 symbol indices: alphabets up to 65536 (lookup tables in device memory) --------------------------
+extern "C" int scl_tans_encode_batch_u16(const scl_tans_model *m, const uint16_t *d_sym, uint64_t sym_stride,
+                                         const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                         uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                         uint32_t *d_out_nbits, uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits,
+                "tans_encode_batch_u16: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "tans_encode_batch_u16")) return rc_dev;
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride * 8 < (1ull << 32),
+                "tans_encode_batch_u16: bad out_stride %llu", (unsigned long long)out_stride);
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_sym & 1) == 0,
+                "tans_encode_batch_u16: d_out must be 16-byte aligned, d_sym 2-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    SCL_REQUIRE(m->tables, "tans_encode_batch_u16: this model has no lookup tables (RANGE_FACTOR*M > 2^26)");
+    if (int rc = tans_ensure_tables(m)) return rc;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    hipLaunchKernelGGL(tans_encode_kernel<u16>, dim3(blocks), dim3(threads), 16, (hipStream_t)stream, m->dev, d_sym,
+                       sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
+                       d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_tans_decode_batch_u16(const scl_tans_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
+                                         const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                         uint64_t n_chunks, uint16_t *d_out_sym, uint64_t out_stride,
+                                         uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                         uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "tans_decode_batch_u16: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "tans_decode_batch_u16")) return rc_dev;
+    SCL_REQUIRE(((uintptr_t)d_in & 3) == 0 && ((uintptr_t)d_out_sym & 1) == 0,
+                "tans_decode_batch_u16: d_in must be 4-byte aligned, d_out_sym 2-byte aligned");
+    if (n_chunks == 0) return SCL_OK;
+    SCL_REQUIRE(m->tables, "tans_decode_batch_u16: this model has no lookup tables (RANGE_FACTOR*M > 2^26)");
+    if (int rc = tans_ensure_tables(m)) return rc;
+    const u32 threads = 256;
+    const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
+    const u32 lds = (m->dev.lds_tables ? 2 * m->dev.L : 4) * sizeof(u32);
+    hipLaunchKernelGGL(tans_decode_kernel<u16>, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, m->dev, d_in,
+                       in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
+                       d_consumed, d_status);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
 }
 
 // ---- single-chunk host drivers --------------------------------------------------------------------------
@@ -440,4 +511,30 @@ extern "C" int scl_tans_decode_host(const scl_tans_model *m, const uint8_t *h_in
                                     uint8_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
     HostDecodeCall call = {tans_run_dec, nullptr};
     return scl_host_decode_one(call, m, h_in, in_nbits, h_out_sym, out_cap, n_out, consumed);
+}
+
+static int tans_run_enc16(const void *model, const u8 *d_sym, u32 n, u8 *d_out, u64 out_stride, u64 *d_bit_off,
+                          u32 *d_nbits, u32 *d_status, void *, u64) {
+    return scl_tans_encode_batch_u16((const scl_tans_model *)model, (const u16 *)d_sym, n, nullptr, n, 1, d_out,
+                                     out_stride, d_bit_off, d_nbits, d_status, nullptr);
+}
+static int tans_run_dec16(const void *model, const u8 *d_in, u64 in_bytes, const u64 *d_bit_off, const u32 *d_in_nbits,
+                          u8 *d_out_sym, u32 out_cap, u32 *d_out_len, u32 *d_consumed, u32 *d_status, void *, u64) {
+    return scl_tans_decode_batch_u16((const scl_tans_model *)model, d_in, in_bytes, d_bit_off, d_in_nbits, 1,
+                                     (u16 *)d_out_sym, (u64)out_cap + 1, out_cap, d_out_len, d_consumed, d_status,
+                                     nullptr);
+}
+
+extern "C" int scl_tans_encode_host_u16(const scl_tans_model *m, const uint16_t *h_sym, uint64_t n, uint8_t *h_out,
+                                        uint64_t out_cap_bytes, uint64_t *nbits) {
+    HostEncodeCall call = {tans_run_enc16, tans_slot, nullptr};
+    call.sym_bytes = 2;
+    return scl_host_encode_one(call, m, (const u8 *)h_sym, n, h_out, out_cap_bytes, nbits);
+}
+
+extern "C" int scl_tans_decode_host_u16(const scl_tans_model *m, const uint8_t *h_in, uint64_t in_nbits,
+                                        uint16_t *h_out_sym, uint64_t out_cap, uint64_t *n_out, uint64_t *consumed) {
+    HostDecodeCall call = {tans_run_dec16, nullptr};
+    call.sym_bytes = 2;
+    return scl_host_decode_one(call, m, h_in, in_nbits, (u8 *)h_out_sym, out_cap, n_out, consumed);
 }

@@ -19,11 +19,12 @@ from stanford_compression_library_amd.utils.bitarray_utils import BitArray
 
 pytestmark = pytest.mark.gpu
 
-RANS = load_golden("rans")
-TANS = [c for c in load_golden("tans") if c.kind == "tans"]
+WIDE = load_golden("wide")  # G11: alphabets of 300..1000 symbols (uint16 indices, the *_u16 entry points)
+RANS = load_golden("rans") + [c for c in WIDE if c.kind == "rans"]
+TANS = [c for c in load_golden("tans") if c.kind == "tans"] + [c for c in WIDE if c.kind == "tans"]
 TANS_TABLES = [c for c in load_golden("tans") if c.kind == "tans_tables"]
-RANGE = load_golden("range")
-AEC = load_golden("aec")
+RANGE = load_golden("range") + [c for c in WIDE if c.kind == "range"]
+AEC = load_golden("aec") + [c for c in WIDE if c.kind == "aec"]
 
 
 def _alphabet(K):

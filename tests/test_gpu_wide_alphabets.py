@@ -1,0 +1,296 @@
+"""GPU parity for alphabets of more than 256 symbols: the *_u16 entry points of include/scl_hip.h (uint16 symbol indices,
+any-parameter kernels) against the CPU oracle's *_w16 functions -- which tests/test_oracle_goldens.py pins on vectors the
+reference itself produced for 300..1000-symbol alphabets (tests/golden/golden_wide.npz, group G11).  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scl_oracle as orc
+from stanford_compression_library_amd.backend import lib as backend_lib
+from stanford_compression_library_amd.backend import models
+from stanford_compression_library_amd.compressors.arithmetic_coding import (AECParams, ArithmeticDecoder,
+                                                                             ArithmeticEncoder)
+from stanford_compression_library_amd.compressors.probability_models import (AdaptiveIIDFreqModel,
+                                                                               AdaptiveOrderKFreqModel)
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.prob_dist import Frequencies
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    backend_lib.require_device()
+    return torch.device("cuda:0")
+
+
+def _stream_bits(data_np, bit_off, nbits):
+    first = int(bit_off) // 8
+    bits = np.unpackbits(data_np[first:(int(bit_off) + int(nbits) + 7) // 8 + 1])
+    lo = int(bit_off) - 8 * first
+    return bits[lo:lo + int(nbits)]
+
+
+def _table(K, total_log2, seed):
+    """K frequencies >= 1 summing to 2^total_log2"""
+    rng = np.random.default_rng(seed)
+    f = np.ones(K, dtype=np.int64)
+    np.add.at(f, rng.integers(0, K, (1 << total_log2) - K), 1)
+    assert f.sum() == 1 << total_log2
+    return f
+
+
+# name -> (K, frequency table, model, oracle encode, oracle decode)
+def _cases():
+    f300, f1000, f4096, f65536 = _table(300, 12, 1), _table(1000, 12, 2), _table(4096, 14, 3), np.ones(65536, np.int64)
+    ones = lambda K: np.ones(K, dtype=np.int64)
+    return {
+        "rans_K300": (f300, lambda: models.RansModel(f300.tolist(), 1 << 16, 1, 32),
+                      lambda s: orc.rans_encode(s, f300), lambda p, n: orc.rans_decode(p, n, f300)),
+        "rans_K1000_b4": (f1000, lambda: models.RansModel(f1000.tolist(), 1 << 10, 4, 24),
+                          lambda s: orc.rans_encode(s, f1000, RF=1 << 10, b=4, size_bits=24),
+                          lambda p, n: orc.rans_decode(p, n, f1000, RF=1 << 10, b=4, size_bits=24)),
+        "rans_K65536_u64": (f65536, lambda: models.RansModel(f65536.tolist(), 1 << 20, 16, 32),
+                            lambda s: orc.rans_encode(s, f65536, RF=1 << 20, b=16),
+                            lambda p, n: orc.rans_decode(p, n, f65536, RF=1 << 20, b=16)),
+        "tans_K1000_rf1": (f1000, lambda: models.TansModel(f1000.tolist(), 1, 32),
+                           lambda s: orc.tans_encode(s, f1000, RF=1), lambda p, n: orc.tans_decode(p, n, f1000, RF=1)),
+        "tans_K4096_rf8": (f4096, lambda: models.TansModel(f4096.tolist(), 8, 32),
+                           lambda s: orc.tans_encode(s, f4096, RF=8), lambda p, n: orc.tans_decode(p, n, f4096, RF=8)),
+        "range_K1000": (f1000, lambda: models.RangeModel(f1000.tolist(), 32, 32),
+                        lambda s: orc.range_encode(s, f1000), lambda p, n: orc.range_decode(p, n, f1000)),
+        "range_K65536_p48": (f65536, lambda: models.RangeModel(f65536.tolist(), 48, 20),
+                             lambda s: orc.range_encode(s, f65536, precision=48, size_bits=20),
+                             lambda p, n: orc.range_decode(p, n, f65536, precision=48, size_bits=20)),
+        "aec_fixed_K1000": (f1000, lambda: models.AecModel(0, f1000.tolist(), 1000, 0, 1 << 30, 32, 32),
+                            lambda s: orc.aec_encode(s, orc.MODEL_FIXED, 1000, f_init=f1000),
+                            lambda p, n: orc.aec_decode(p, n, orc.MODEL_FIXED, 1000, f_init=f1000)),
+        "aec_iid_K300": (f300, lambda: models.AecModel(1, [1] * 300, 300, 0, 1 << 30, 32, 32),
+                         lambda s: orc.aec_encode(s, orc.MODEL_IID, 300, f_init=ones(300)),
+                         lambda p, n: orc.aec_decode(p, n, orc.MODEL_IID, 300, f_init=ones(300))),
+        "aec_iid_K300_halving": (f300, lambda: models.AecModel(1, [1] * 300, 300, 0, 1 << 9, 16, 32),
+                                 lambda s: orc.aec_encode(s, orc.MODEL_IID, 300, f_init=ones(300), max_total=1 << 9,
+                                                          precision=16),
+                                 lambda p, n: orc.aec_decode(p, n, orc.MODEL_IID, 300, f_init=ones(300), max_total=1 << 9,
+                                                             precision=16)),
+        "aec_order1_K300": (f300, lambda: models.AecModel(2, None, 300, 1, 1 << 30, 32, 32),
+                            lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, 300, k=1),
+                            lambda p, n: orc.aec_decode(p, n, orc.MODEL_ORDERK, 300, k=1)),
+        "aec_order1_K300_p48": (f300, lambda: models.AecModel(2, None, 300, 1, 1 << 40, 48, 32),
+                                lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, 300, k=1, max_total=1 << 40, precision=48),
+                                lambda p, n: orc.aec_decode(p, n, orc.MODEL_ORDERK, 300, k=1, max_total=1 << 40,
+                                                            precision=48)),
+    }
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_batch_ragged_vs_oracle_wide(name, dev):
+    """ragged chunks (incl. empty and one-symbol ones) in one launch through the uint16 entry points: every stream
+    equals the oracle's; decoding from the slots, and from a dense buffer with 37 garbage bits after every stream,
+    returns the symbols and the exact bit count"""
+    freq, make_model, o_enc, o_dec = CASES[name]
+    K = freq.size
+    model = make_model()
+    assert model.wide and model.sym_dtype == np.uint16
+    rng = np.random.default_rng(21)
+    lens = np.array([0, 1, 2, 3, 7, 64, 65, 100, 255, 256, 257, 300, 301, 333, 400, 17], dtype=np.int32)
+    cap = 400
+    p = freq / freq.sum()
+    sym = rng.choice(K, size=(len(lens), cap), p=p).astype(np.uint16)
+    sym[3, :3] = [K - 1, 0, K - 1]  # both ends of the alphabet
+    d_sym = torch.from_numpy(sym).to(dev)
+    enc = model.encode_batch(d_sym, lens=torch.from_numpy(lens).to(dev))
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0
+    data = enc.data.cpu().numpy()
+    offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    ref = [o_enc(sym[c, :lens[c]]) for c in range(len(lens))]
+    for c, (rb, rn) in enumerate(ref):
+        assert int(nbits[c]) == rn, f"chunk {c}: {nbits[c]} bits vs oracle {rn}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert dec.dtype == torch.uint16
+    assert int(status.abs().sum()) == 0
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    assert np.array_equal(used.cpu().numpy(), nbits)
+    dec = dec.cpu().numpy()
+    for c in range(len(lens)):
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]])
+    pieces, new_off, new_avail, pos = [], [], [], 0
+    for c, (rb, rn) in enumerate(ref):
+        g = rng.integers(0, 2, 37).astype(np.uint8)
+        pieces += [np.unpackbits(rb)[:rn], g]
+        new_off.append(pos)
+        new_avail.append(rn + 37)
+        pos += rn + 37
+    packed = np.packbits(np.concatenate(pieces))
+    buf = torch.zeros(packed.size + 32, dtype=torch.uint8, device=dev)
+    buf[:packed.size] = torch.from_numpy(packed).to(dev)
+    dec2, dlens2, used2, status2 = model.decode_batch(buf, torch.tensor(new_off, dtype=torch.int64, device=dev),
+                                                      torch.tensor(new_avail, dtype=torch.int32, device=dev), cap)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    used2, dec2 = used2.cpu().numpy(), dec2.cpu().numpy()
+    for c, (rb, rn) in enumerate(ref):
+        if lens[c] == 0 and name.startswith("aec"):
+            continue  # quirk Q5: the reference never terminates on an empty arithmetic-coded block
+        o_sym, o_used = o_dec(np.packbits(np.concatenate([np.unpackbits(rb)[:rn], pieces[2 * c + 1]])), rn + 37)
+        assert used2[c] == o_used == rn
+        assert np.array_equal(dec2[c, :lens[c]], sym[c, :lens[c]]) and np.array_equal(o_sym, sym[c, :lens[c]])
+
+
+def _call_u16(model, sym16, lens, dev):
+    """the *_u16 batch encoder called directly on ANY model handle (also one of at most 256 symbols)"""
+    L = backend_lib.load()
+    n, width = sym16.shape
+    d_sym = torch.from_numpy(sym16).to(dev)
+    d_lens = torch.from_numpy(lens).to(dev)
+    out = model.alloc_encoded(n, width, dev)
+    args = [model._h, d_sym.data_ptr(), width, d_lens.data_ptr(), width, n, out.data.data_ptr(), out.stride,
+            out.bit_offset.data_ptr(), out.nbits.data_ptr(), out.status.data_ptr()]
+    scratch = None
+    if model._needs_scratch:
+        nbytes = int(L.scl_aec_scratch_bytes(model._h, n))
+        scratch = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        args += [scratch.data_ptr(), nbytes]
+    rc = getattr(L, f"scl_{model._prefix}_encode_batch_u16")(*args, None)
+    backend_lib.check(rc, "encode_batch_u16")
+    torch.cuda.synchronize()
+    return out
+
+
+SMALL = {
+    "rans": lambda f: models.RansModel(f.tolist(), 1 << 16, 1, 32),
+    "rans_b8": lambda f: models.RansModel(f.tolist(), 1 << 8, 8, 32),
+    "tans": lambda f: models.TansModel(f.tolist(), 2, 32),
+    "range": lambda f: models.RangeModel(f.tolist(), 32, 32),
+    "aec_fixed": lambda f: models.AecModel(0, f.tolist(), f.size, 0, 1 << 30, 32, 32),
+    "aec_iid": lambda f: models.AecModel(1, [1] * f.size, f.size, 0, 1 << 30, 32, 32),
+    "aec_order1_K5": lambda f: models.AecModel(2, None, 5, 1, 1 << 30, 32, 32),
+    "aec_order1_two_level_rows": lambda f: models.AecModel(2, None, f.size, 1, 1 << 30, 32, 32),
+}
+
+
+@pytest.mark.parametrize("name", list(SMALL))
+def test_u16_entry_points_equal_u8_on_small_alphabets(name, dev):
+    """a model of at most 256 symbols coded through the uint16 entry points gives, bit for bit, the stream of the uint8
+    entry points (tuned kernels) -- the two symbol widths are two views of one coder"""
+    K = 5 if name.endswith("K5") else 200
+    f = _table(K, 12, 5)
+    model = SMALL[name](f)
+    assert not model.wide
+    rng = np.random.default_rng(6)
+    lens = np.array([0, 1, 5, 64, 129, 300, 512, 511], dtype=np.int32)
+    sym = rng.choice(K, size=(len(lens), 512), p=f / f.sum()).astype(np.uint8)
+    enc8 = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    torch.cuda.synchronize()
+    enc16 = _call_u16(model, sym.astype(np.uint16), lens, dev)
+    assert int(enc8.status.abs().sum()) == 0 and int(enc16.status.abs().sum()) == 0
+    assert np.array_equal(enc8.nbits.cpu().numpy(), enc16.nbits.cpu().numpy())
+    d8, d16 = enc8.data.cpu().numpy(), enc16.data.cpu().numpy()
+    o8, o16, nb = enc8.bit_offset.cpu().numpy(), enc16.bit_offset.cpu().numpy(), enc8.nbits.cpu().numpy()
+    for c in range(len(lens)):
+        assert np.array_equal(_stream_bits(d8, o8[c], nb[c]), _stream_bits(d16, o16[c], nb[c])), f"chunk {c}"
+
+
+def test_u8_entry_points_refuse_wide_models_and_symbols_are_range_checked(dev):
+    L = backend_lib.load()
+    f = _table(300, 12, 1)
+    model = models.RansModel(f.tolist(), 1 << 16, 1, 32)
+    sym8 = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
+    out = model.alloc_encoded(2, 64, dev)
+    rc = L.scl_rans_encode_batch(model._h, sym8.data_ptr(), 64, None, 64, 2, out.data.data_ptr(), out.stride,
+                                 out.bit_offset.data_ptr(), out.nbits.data_ptr(), out.status.data_ptr(), None)
+    assert rc == backend_lib.E_PARAM and "scl_rans_encode_batch_u16" in backend_lib.last_error()
+    # index 300 is outside the alphabet: SCL_ST_SYMBOL for that chunk only (KeyError in the reference)
+    sym = np.zeros((2, 64), dtype=np.uint16)
+    sym[1, 7] = 300
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev))
+    torch.cuda.synchronize()
+    assert enc.status.cpu().numpy().tolist() == [0, backend_lib.ST_SYMBOL]
+    # alphabets above 65536 symbols are refused at model creation
+    h = C.c_void_p()
+    big = np.ones(65537, dtype=np.uint32)
+    assert L.scl_rans_model_create(backend_lib.u32_ptr(big), 65537, 1, 1, 32, C.byref(h)) == backend_lib.E_PARAM
+
+
+def test_drop_in_classes_on_a_thousand_symbol_alphabet(dev):
+    """the class API with an alphabet of 1000 hashable symbols: encode_block / decode_block against the oracle,
+    including an adaptive arithmetic coder whose model object lives across two blocks (quirk Q4)"""
+    K = 1000
+    alphabet = [("tok", i) for i in range(K)]  # any hashable
+    f = _table(K, 12, 8)
+    fr = Frequencies(dict(zip(alphabet, f.tolist())))
+    rng = np.random.default_rng(9)
+    idx = rng.choice(K, size=700, p=f / f.sum())
+    block = DataBlock([alphabet[i] for i in idx])
+
+    def check(enc, make_dec, o_stream):
+        bits = enc.encode_block(block)
+        assert len(bits) == o_stream[1] and np.array_equal(bits.packed(), o_stream[0])
+        out, used = make_dec().decode_block(bits)
+        assert used == len(bits) and out.data_list == block.data_list
+
+    rp = rANSParams(fr)
+    check(rANSEncoder(rp), lambda: rANSDecoder(rp), orc.rans_encode(idx, f))
+    tp = tANSParams(fr, RANGE_FACTOR=4)
+    check(tANSEncoder(tp), lambda: tANSDecoder(tp), orc.tans_encode(idx, f, RF=4))
+    cp = RangeCoderParams()
+    check(RangeEncoder(cp, fr), lambda: RangeDecoder(cp, fr), orc.range_encode(idx, f))
+    ap = AECParams()
+    ones = Frequencies(dict(zip(alphabet, [1] * K)))
+    enc = ArithmeticEncoder(ap, AdaptiveIIDFreqModel(ones, ap.MAX_ALLOWED_TOTAL_FREQ))
+    dec = ArithmeticDecoder(ap, AdaptiveIIDFreqModel(ones, ap.MAX_ALLOWED_TOTAL_FREQ))
+    st_e = orc.aec_fresh_state(orc.MODEL_IID, K, 0, np.ones(K))
+    for part in (idx[:300], idx[300:]):  # two blocks, ONE coder object on each side
+        blk = DataBlock([alphabet[i] for i in part])
+        bits = enc.encode_block(blk)
+        ob, on = orc.aec_encode(part, orc.MODEL_IID, K, f_init=np.ones(K), state=st_e)
+        assert len(bits) == on and np.array_equal(bits.packed(), ob)
+        out, used = dec.decode_block(bits)
+        assert used == len(bits) and out.data_list == blk.data_list
+    small = [("tok", i) for i in range(260)]
+    enc = ArithmeticEncoder(ap, AdaptiveOrderKFreqModel(small, 1, ap.MAX_ALLOWED_TOTAL_FREQ))
+    dec = ArithmeticDecoder(ap, AdaptiveOrderKFreqModel(small, 1, ap.MAX_ALLOWED_TOTAL_FREQ))
+    st_e = orc.aec_fresh_state(orc.MODEL_ORDERK, 260, 1)
+    idx2 = rng.integers(0, 260, 500)
+    for part in (idx2[:200], idx2[200:]):
+        blk = DataBlock([small[i] for i in part])
+        bits = enc.encode_block(blk)
+        ob, on = orc.aec_encode(part, orc.MODEL_ORDERK, 260, k=1, state=st_e)
+        assert len(bits) == on and np.array_equal(bits.packed(), ob)
+        out, used = dec.decode_block(bits)
+        assert used == len(bits) and out.data_list == blk.data_list
+
+
+def test_block_loop_on_a_wide_alphabet(dev, tmp_path):
+    """DataEncoder.encode / DataDecoder.decode (the batched stream driver: all blocks of a file in one launch) with
+    600 symbols: the file decodes back, and every framed block equals the oracle's stream"""
+    from conftest import frame_blocks
+    from stanford_compression_library_amd.core.data_stream import ListDataStream
+    from stanford_compression_library_amd.core.encoded_stream import EncodedBlockReader, EncodedBlockWriter
+
+    K = 600
+    f = _table(K, 12, 10)
+    fr = Frequencies(dict(zip(range(K), f.tolist())))
+    idx = np.random.default_rng(11).choice(K, size=2500, p=f / f.sum())
+    p = rANSParams(fr)
+    path = str(tmp_path / "wide.bin")
+    with EncodedBlockWriter(path) as w:
+        rANSEncoder(p).encode(ListDataStream(idx.tolist()), 1000, w)
+    blocks = [orc.rans_encode(idx[a:a + 1000], f) for a in range(0, idx.size, 1000)]
+    assert np.array_equal(np.fromfile(path, dtype=np.uint8), frame_blocks(blocks))
+    out = ListDataStream([])
+    with EncodedBlockReader(path) as r:
+        rANSDecoder(p).decode(r, out)
+    assert out.input_list == idx.tolist()

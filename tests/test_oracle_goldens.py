@@ -7,11 +7,12 @@ import pytest
 import scl_oracle as orc
 from conftest import golden_ids, load_golden
 
-RANS = [c for c in load_golden("rans")]
-TANS = [c for c in load_golden("tans") if c.kind == "tans"]
+WIDE = load_golden("wide")  # G11: alphabets above 256 symbols (uint16 indices; the oracle's *_w16 entry points)
+RANS = [c for c in load_golden("rans")] + [c for c in WIDE if c.kind == "rans"]
+TANS = [c for c in load_golden("tans") if c.kind == "tans"] + [c for c in WIDE if c.kind == "tans"]
 TANS_TABLES = [c for c in load_golden("tans") if c.kind == "tans_tables"]
-RANGE = load_golden("range")
-AEC = load_golden("aec")
+RANGE = load_golden("range") + [c for c in WIDE if c.kind == "range"]
+AEC = load_golden("aec") + [c for c in WIDE if c.kind == "aec"]
 MODEL = {"fixed": orc.MODEL_FIXED, "iid": orc.MODEL_IID, "orderk": orc.MODEL_ORDERK}
 
 
