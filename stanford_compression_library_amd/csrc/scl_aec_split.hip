@@ -10,15 +10,17 @@
 //   model  : look up (c, d, T) for the symbol, count it            -- independent of the coder state, can run ahead
 //   coder  : shrink_range, count the renormalisation steps, new (low, high)   -- the only serial state
 //   writer : turn (top bits of low, k, pending) into stream bits, store words -- consumes, never feeds back
-// So a workgroup of 768 lanes serves 256 chunks: lane L of waves 0-3 owns the tables of chunk L, lane L of waves 4-7
-// its (low, high, pending), lane L of waves 8-11 its output window -- three waves per SIMD over the same tables, each
-// running a third of the instruction stream.  The roles meet in two double-buffered LDS FIFOs, AS_TILE symbols per
+// So a workgroup of 3 AS_LANES lanes serves AS_LANES chunks: lane L of the model wave(s) owns the tables of chunk L, lane
+// L of the coder wave(s) its (low, high, pending), lane L of the writer wave(s) its output window -- three waves per SIMD
+// over the same tables, each running a third of the instruction stream.  AS_LANES = 64 (one wave per role, four 40 KiB
+// workgroups per CU whose barriers are independent) measured 2 % faster than one 768-lane workgroup per CU; 128 is much
+// slower (8.1 vs 5.1 ms: six-wave workgroups land their roles unevenly on the four SIMDs).  The roles meet in two double-buffered LDS FIFOs, AS_TILE symbols per
 // lane and barrier: in round r the model fills tile r, the coder drains tile r - 1, the writer tile r - 2.
 // Measured (profiles/r03_aec_split_note.txt): 7.9 -> 5.3 ms per GiB of order-1 K = 16 data; the roles alone take
 // 0.86 (model) / ~0.9 / ~0.9 ms per 256 MiB, all three together 1.38 -- the VALU is ~70 % busy, the rest is LDS time.
 //
 // Model side.  Context rows are 16 u16 EXCLUSIVE cumulative counts as in scl_aec_fast.hip, but laid out in planes:
-// word w (two counts) of context `ctx` of lane t at (ctx * 8 + w) * 1 KiB + 4 t -- every 4-byte access of a wave is
+// word w (two counts) of context `ctx` of lane t at (ctx * 8 + w) * AS_PLANE + 4 t -- every 4-byte access of a wave is
 // conflict free whatever the lanes' contexts and symbols.  `count[s] += 1` is X[j] += 1 for j > s: eight ds_add_u32
 // with an addend row from a 512-byte LUT (no read-modify-write through registers, so all LDS traffic of a tile is
 // issued back to back and waited for once); c = X[s], d = X[s + 1] come out of ONE two-word read (ds_read2st64) and
@@ -33,8 +35,10 @@
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
 
-#define AS_LANES 256                   // chunks per workgroup
-#define AS_THREADS (3 * AS_LANES)      // waves 0-3: model role, waves 4-7: coder role, waves 8-11: writer role
+#ifndef AS_LANES
+#define AS_LANES 64                    // chunks per workgroup: one wave per role, four workgroups per CU (40 KiB of LDS each)
+#endif
+#define AS_THREADS (3 * AS_LANES)      // wave 0: model role, wave 1: coder role, wave 2: writer role
 #define AS_PLANE (AS_LANES * 4)        // one u32 of every chunk
 #define AS_ROW_BYTES (8 * AS_PLANE)    // 8 KiB per context
 #define AS_TABLE_BYTES (16 * AS_ROW_BYTES)
