@@ -294,3 +294,75 @@ def test_block_loop_on_a_wide_alphabet(dev, tmp_path):
     with EncodedBlockReader(path) as r:
         rANSDecoder(p).decode(r, out)
     assert out.input_list == idx.tolist()
+
+
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 14))))
+def test_random_wide_models_vs_oracle(seed, dev):
+    """Differential test of the uint16 entry points on random models: alphabets of 257..6000 symbols, random parameter
+    sets of all four coders (u32 and u64 states, NUM_BITS_OUT, RANGE_FACTOR, PRECISION, DATA_BLOCK_SIZE_BITS, adaptive
+    models with random initial counts, order-k), 12 ragged chunks each; streams, symbols and consumed-bit counts against
+    the oracle.  SCL_RANDOM_SEEDS=200 turns it into a campaign."""
+    rng = np.random.default_rng(70000 + seed)
+    cap = 300
+    lens = np.concatenate([[0, 1, 2, 129, 300], rng.integers(0, cap + 1, 7)]).astype(np.int32)
+    sb = int(rng.choice([32, 9, 17, 24]))
+    coder = ["rans", "tans", "range", "aec_fixed", "aec_iid", "aec_orderk", "rans"][seed % 7]
+    K = int(rng.integers(257, 6001)) if coder != "aec_orderk" else int(rng.integers(257, 400))
+
+    def table(total):
+        f = np.ones(K, dtype=np.int64)
+        np.add.at(f, rng.integers(0, K, total - K), 1)
+        return f
+
+    if coder == "rans":
+        f = table(int(rng.integers(K, 1 << 16)))
+        b = int(rng.choice([1, 2, 4, 8, 16]))
+        RF = 1 << int(rng.integers(0, 30))
+        if (RF * int(f.sum())) << b >= 1 << 63:
+            RF = 1 << 8
+        model = models.RansModel(f.tolist(), RF, b, sb)
+        o_enc = lambda s: orc.rans_encode(s, f, RF=RF, b=b, size_bits=sb)
+        o_dec = lambda p, n: orc.rans_decode(p, n, f, RF=RF, b=b, size_bits=sb)
+    elif coder == "tans":
+        m = int(rng.integers(int(np.ceil(np.log2(K))), 15))
+        f = table(1 << m)
+        RF = 1 << int(rng.integers(0, 19 - m))
+        model = models.TansModel(f.tolist(), RF, sb)
+        o_enc = lambda s: orc.tans_encode(s, f, RF=RF, size_bits=sb)
+        o_dec = lambda p, n: orc.tans_decode(p, n, f, RF=RF, size_bits=sb)
+    elif coder == "range":
+        prec = int(rng.choice([32, 40, 48, 64]))
+        f = table(int(rng.integers(K, 1 << 16)))
+        model = models.RangeModel(f.tolist(), prec, sb)
+        o_enc = lambda s: orc.range_encode(s, f, precision=prec, size_bits=sb)
+        o_dec = lambda p, n: orc.range_decode(p, n, f, precision=prec, size_bits=sb)
+    else:
+        prec = int(rng.choice([32, 32, 24, 40]))
+        mt = 1 << (prec - 2)
+        kind = {"aec_fixed": orc.MODEL_FIXED, "aec_iid": orc.MODEL_IID, "aec_orderk": orc.MODEL_ORDERK}[coder]
+        f = table(int(rng.integers(K, min(1 << 16, mt // 2)))) if coder != "aec_orderk" else np.ones(K, dtype=np.int64)
+        k = 1 if coder == "aec_orderk" else 0
+        model = models.AecModel(kind, None if coder == "aec_orderk" else f.tolist(), K, k, mt, prec, sb)
+        o_enc = lambda s: orc.aec_encode(s, kind, K, k=k, f_init=f, max_total=mt, precision=prec, size_bits=sb)
+        o_dec = lambda p, n: orc.aec_decode(p, n, kind, K, k=k, f_init=f, max_total=mt, precision=prec, size_bits=sb)
+    assert model.wide
+    p = rng.dirichlet(np.full(K, float(rng.choice([0.05, 1.0]))))
+    sym = rng.choice(K, (lens.size, cap), p=p).astype(np.uint16)
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    what = f"{coder} K={K} size_bits={sb}"
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0, what
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    assert np.array_equal(dlens.cpu().numpy(), lens), what
+    for c in range(lens.size):
+        rb, rn = o_enc(sym[c, :lens[c]])
+        assert int(nbits[c]) == rn, f"{what} chunk {c}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{what} chunk {c}"
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{what} chunk {c}"
+        if lens[c] > 0 or not coder.startswith("aec"):
+            assert used[c] == o_dec(rb, rn)[1], f"{what} chunk {c}"
