@@ -307,6 +307,10 @@ int scl_streams_gather_blocks_rccl(scl_comm *c, int root, const uint8_t *d_paylo
 /* d_counts[256] (uint64) += number of occurrences of every byte value in d_sym[0..n).  The caller zeroes
    d_counts.  Equals DataBlock.get_counts() (scl/core/data_block.py:37-62) for uint8 data. */
 int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_counts, void *stream);
+/* the same for uint16 symbol indices of an alphabet of K <= 65536 symbols: d_counts[K] += occurrences; indices >= K are
+   not counted but tallied in *d_out_of_range (uint32, zeroed by the caller).  ABI 4. */
+int scl_histogram_u16(const uint16_t *d_sym, uint64_t n, uint32_t K, uint64_t *d_counts,
+                      uint32_t *d_out_of_range, void *stream);
 
 /* ---- host convenience (one chunk, host buffers; allocates, copies, runs N=1, synchronises) --- */
 /* These back the drop-in encode_block / decode_block of the Python classes.  h_out receives the

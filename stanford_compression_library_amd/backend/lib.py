@@ -95,6 +95,7 @@ _SIGNATURES = {
     "scl_streams_compact": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp]),
     "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),
     "scl_histogram_u8": (_int, [_vp, _u64, _vp, _vp]),
+    "scl_histogram_u16": (_int, [_vp, _u64, _u32, _vp, _vp, _vp]),
     "scl_rccl_unique_id": (_int, [_u8p]),
     "scl_rccl_comm_create": (_int, [_u8p, _int, _int, C.POINTER(_vp)]),
     "scl_rccl_comm_destroy": (None, [_vp]),

@@ -4,7 +4,8 @@ The reference offers ``DataBlock.get_counts`` / ``get_empirical_distribution`` (
 Python loops) and *no* frequency normaliser, although tANS asserts a power-of-two total (tANS.py:42-44) and the
 range coder needs ``total <= 2**16``.  This module adds the two missing pieces:
 
-* ``histogram_u8`` -- byte counts on the device (``scl_histogram_u8``); equals ``DataBlock.get_counts()``;
+* ``histogram_u8`` / ``histogram_u16`` -- symbol counts on the device (``scl_histogram_u8`` for bytes, ``scl_histogram_u16``
+  for alphabets up to 65536 symbols); equal ``DataBlock.get_counts()``;
 * ``normalize_counts`` -- a deterministic quantiser to a given total M (every present symbol keeps f >= 1,
   largest-remainder rounding, ties broken by symbol index), so encoder and decoder rebuild identical tables
   from the same counts.
@@ -26,6 +27,23 @@ def histogram_u8(sym) -> np.ndarray:
     rc = _lib.load().scl_histogram_u8(sym.data_ptr(), sym.numel(), counts.data_ptr(),
                                       torch.cuda.current_stream(sym.device).cuda_stream)
     _lib.check(rc, "scl_histogram_u8")
+    return counts.cpu().numpy()
+
+
+def histogram_u16(sym, K: int) -> np.ndarray:
+    """uint16 (or int16) CUDA tensor of alphabet indices < K (any shape, contiguous) -> int64[K] counts
+    (``scl_histogram_u16``: alphabets up to 65536 symbols); an index >= K raises ``KeyError`` like
+    ``Frequencies.frequency`` (prob_dist.py:207-208)."""
+    import torch
+
+    assert sym.is_cuda and sym.dtype in (torch.uint16, torch.int16) and sym.is_contiguous()
+    counts = torch.zeros(int(K), dtype=torch.int64, device=sym.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=sym.device)
+    rc = _lib.load().scl_histogram_u16(sym.data_ptr(), sym.numel(), int(K), counts.data_ptr(), bad.data_ptr(),
+                                       torch.cuda.current_stream(sym.device).cuda_stream)
+    _lib.check(rc, "scl_histogram_u16")
+    if int(bad.item()):
+        raise KeyError(f"{int(bad.item())} symbol indices outside the alphabet of {K}")
     return counts.cpu().numpy()
 
 

@@ -385,6 +385,45 @@ extern "C" int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_co
     return SCL_OK;
 }
 
+// uint16 symbol indices (alphabets up to 65536, ABI 4): workgroup-private u32 histograms in LDS when the alphabet fits
+// (K <= 16384: 64 KiB), one global atomic per non-zero bin per workgroup; larger alphabets count straight into HBM.
+__global__ void __launch_bounds__(256) histogram_u16_kernel(const u16 *__restrict__ sym, u64 n, u32 K, u32 lds_bins,
+                                                           unsigned long long *__restrict__ counts,
+                                                           u32 *__restrict__ bad) {
+    extern __shared__ u32 s_bins[];
+    for (u32 i = threadIdx.x; i < lds_bins; i += 256) s_bins[i] = 0;
+    __syncthreads();
+    u32 n_bad = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const u32 s = sym[i];
+        if (s >= K)
+            ++n_bad;
+        else if (lds_bins)
+            atomicAdd(&s_bins[s], 1u);
+        else
+            atomicAdd(&counts[s], 1ull);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < lds_bins; i += 256)
+        if (s_bins[i]) atomicAdd(&counts[i], (unsigned long long)s_bins[i]);
+}
+
+extern "C" int scl_histogram_u16(const uint16_t *d_sym, uint64_t n, uint32_t K, uint64_t *d_counts,
+                                 uint32_t *d_out_of_range, void *stream) {
+    SCL_REQUIRE(d_counts && d_out_of_range && (d_sym || n == 0), "histogram_u16: null pointer argument");
+    SCL_REQUIRE(K >= 1 && K <= SCL_MAX_ALPHABET, "histogram_u16: alphabet size %u outside 1..65536", K);
+    SCL_REQUIRE(((uintptr_t)d_sym & 1) == 0, "histogram_u16: d_sym must be 2-byte aligned");
+    if (n == 0) return SCL_OK;
+    u32 blocks = (u32)((n + 4095) / 4096);  // >= 16 symbols per lane
+    if (blocks > 1024) blocks = 1024;
+    const u32 lds_bins = K <= 16384 ? K : 0;
+    hipLaunchKernelGGL(histogram_u16_kernel, dim3(blocks), dim3(256), lds_bins * sizeof(u32), (hipStream_t)stream, d_sym,
+                       n, K, lds_bins, reinterpret_cast<unsigned long long *>(d_counts), d_out_of_range);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
 // ---- host convenience drivers -----------------------------------------------------------------------
 extern "C" int scl_stream_block_size_host(const uint8_t *h_in, uint64_t in_nbits, uint32_t size_bits,
                                           uint64_t *n_out) {

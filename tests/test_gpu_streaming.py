@@ -8,7 +8,8 @@ import pytest
 
 import scl_oracle as orc
 from stanford_compression_library_amd.backend import lib as backend_lib
-from stanford_compression_library_amd.backend.modeling import frequencies_from_counts, histogram_u8, normalize_counts
+from stanford_compression_library_amd.backend.modeling import (frequencies_from_counts, histogram_u8, histogram_u16,
+                                                                normalize_counts)
 from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
 from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
 from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
@@ -90,6 +91,27 @@ def test_histogram_equals_get_counts():
         ref = DataBlock(data.tolist()).get_counts() if n else {}
         assert got.sum() == n and all(got[s] == c for s, c in ref.items())
         assert np.array_equal(got, np.bincount(data, minlength=256))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [257, 1000, 16384, 16385, 65536])
+def test_histogram_u16_equals_get_counts(K):
+    """alphabets above 256 symbols: LDS-private bins up to 16384 symbols, straight global atomics above"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(K)
+    for n in (0, 1, 4097, 300_001):
+        data = rng.integers(0, K, n).astype(np.uint16)
+        if n > 100:
+            data[: n // 2] = K - 1  # a hot symbol, and the last bin
+        got = histogram_u16(torch.from_numpy(data).cuda(), K)
+        assert np.array_equal(got, np.bincount(data, minlength=K))
+        if n == 4097:
+            ref = DataBlock(data.tolist()).get_counts()
+            assert got.sum() == n and all(got[s] == c for s, c in ref.items())
+    if K < 65536:
+        data = np.array([0, K, 3], dtype=np.uint16)
+        with pytest.raises(KeyError):
+            histogram_u16(torch.from_numpy(data).cuda(), K)
 
 
 @pytest.mark.gpu
