@@ -14,8 +14,11 @@
 // L of the coder wave(s) its (low, high, pending), lane L of the writer wave(s) its output window -- three waves per SIMD
 // over the same tables, each running a third of the instruction stream.  AS_LANES = 64 (one wave per role, four 40 KiB
 // workgroups per CU whose barriers are independent) measured 2 % faster than one 768-lane workgroup per CU; 128 is much
-// slower (8.1 vs 5.1 ms: six-wave workgroups land their roles unevenly on the four SIMDs).  The roles meet in two double-buffered LDS FIFOs, AS_TILE symbols per
-// lane and barrier: in round r the model fills tile r, the coder drains tile r - 1, the writer tile r - 2.
+// slower (8.1 vs 5.1 ms: six-wave workgroups land their roles unevenly on the four SIMDs).  The roles meet in two LDS FIFOs, AS_TILE
+// symbols per lane and round: in round r the model fills tile r, the coder drains tile r - 1, the writer tile r - 2.  With
+// one buffer per FIFO (AS_NBUF = 1, shipped: 40 KiB hold tiles of four symbols) a round has two barriers: consumers take
+// their tile into registers, barrier, producers overwrite it, barrier; AS_NBUF = 2 needs one barrier and twice the FIFO
+// space (tiles of two at four workgroups per CU: 5.10 ms, tiles of four at three workgroups: 5.59, shipped form: 4.97).
 // Measured (profiles/r03_aec_split_note.txt): 7.9 -> 5.3 ms per GiB of order-1 K = 16 data; the roles alone take
 // 0.86 (model) / ~0.9 / ~0.9 ms per 256 MiB, all three together 1.38 -- the VALU is ~70 % busy, the rest is LDS time.
 //
@@ -47,19 +50,25 @@
 #define AS_TOT_BYTES (16 * AS_TOT_ROW)
 #define AS_LUT_BASE (AS_TOT_BASE + AS_TOT_BYTES)
 #define AS_LUT_BYTES 512
-#define AS_TILE 2                      // symbols per lane and barrier (two tiles = one 32-bit word of symbols)
+#ifndef AS_TILE
+#define AS_TILE 4                      // symbols per lane and barrier: 2 or 4 (a 32-bit word of symbols is 4 / AS_TILE tiles)
+#endif
+#define AS_RPW (4 / AS_TILE)            // rounds per word of symbols
+#ifndef AS_NBUF
+#define AS_NBUF 1                      // 2: double-buffered FIFOs, one barrier per round; 1: one buffer, consumers take their
+#endif                                 // tile into registers first and a second barrier per round releases the buffer
 #ifndef AS_ABLATE
 #define AS_ABLATE 0  // timing experiments only (outputs invalid), bit mask: 1 no model updates, 2 no coder work, 4 no writer work, 8 no model work at all
 #endif
 // FIFO 1 (model -> coder), two buffers of AS_TILE symbols: 1/T as binary64 [buf][j][lane], c | d << 16 [buf][j][lane]
 #define AS_F1X_BASE (AS_LUT_BASE + AS_LUT_BYTES)
 #define AS_F1X_SLOT (AS_LANES * 8)
-#define AS_F1C_BASE (AS_F1X_BASE + 2 * AS_TILE * AS_F1X_SLOT)
+#define AS_F1C_BASE (AS_F1X_BASE + AS_NBUF * AS_TILE * AS_F1X_SLOT)
 #define AS_F1C_SLOT (AS_LANES * 4)
 // FIFO 2 (coder -> writer): {top k bits of low, k | pending << 8} [buf][j][lane]
-#define AS_F2_BASE (AS_F1C_BASE + 2 * AS_TILE * AS_F1C_SLOT)
+#define AS_F2_BASE (AS_F1C_BASE + AS_NBUF * AS_TILE * AS_F1C_SLOT)
 #define AS_F2_SLOT (AS_LANES * 8)
-#define AS_RED_BASE (AS_F2_BASE + 2 * AS_TILE * AS_F2_SLOT)
+#define AS_RED_BASE (AS_F2_BASE + AS_NBUF * AS_TILE * AS_F2_SLOT)
 #define AS_LDS_BYTES (AS_RED_BASE + 16)
 static_assert(AS_LDS_BYTES <= 160 * 1024, "LDS of one CU");
 
@@ -112,8 +121,9 @@ __global__ void __launch_bounds__(AS_THREADS)
     __syncthreads();
     const u32 nmax = *reinterpret_cast<const u32_lds *>(lds + AS_RED_BASE);
     // round r: the model fills tile r (symbols 2r, 2r + 1), the coder drains tile r - 1, the writer tile r - 2
-    const u32 n_words = (nmax + 3) / 4 + 1;  // two rounds per 32-bit word of symbols; + 1 word drains the pipeline
-    const u32 n_rounds = 2 * n_words;
+    // AS_RPW rounds per 32-bit word of symbols; two more rounds drain the pipeline
+    const u32 n_words = ((nmax + AS_TILE - 1) / AS_TILE + 2 + AS_RPW - 1) / AS_RPW;
+    const u32 n_rounds = AS_RPW * n_words;
 
     if (role == 0) {
         // =============================== model role ===================================================================
@@ -130,8 +140,7 @@ __global__ void __launch_bounds__(AS_THREADS)
         u32 *tot32 = reinterpret_cast<u32 *>(lds + AS_TOT_BASE) + (lane >> 1);
         for (u32 w = 0; w < n_words; ++w) {
             if (AS_ABLATE & 8) {
-                __syncthreads();
-                __syncthreads();
+                for (u32 h = 0; h < AS_RPW * (3 - AS_NBUF); ++h) __syncthreads();
                 continue;
             }
             const u32 word = nextw;
@@ -148,11 +157,13 @@ __global__ void __launch_bounds__(AS_THREADS)
                 lb[q] = *reinterpret_cast<const uint4_lds *>(lds + AS_LUT_BASE + s[q] * 32 + 16);
             }
 #pragma unroll
-            for (u32 half = 0; half < 2; ++half) {
-                u32 w0[2], w1[2], T[2];
+            for (u32 half = 0; half < AS_RPW; ++half) {
+                const u32 buf = (AS_NBUF == 2) ? ((w * AS_RPW + half) & 1) : 0;  // round w * AS_RPW + half fills this FIFO 1 buffer
+                if (AS_NBUF == 1) __syncthreads();  // the coder has taken the previous tile out of FIFO 1
+                u32 w0[AS_TILE], w1[AS_TILE], T[AS_TILE];
 #pragma unroll
-                for (u32 j = 0; j < 2; ++j) {
-                    const u32 q = 2 * half + j;
+                for (u32 j = 0; j < AS_TILE; ++j) {
+                    const u32 q = AS_TILE * half + j;
                     const u32 rowaddr = ctx * AS_ROW_BYTES + lane4;
                     // freqs_current lookup (:118): X[s], X[s + 1] out of words s / 2 and s / 2 + 1, the row total
                     const u32 wa = rowaddr + (s[q] >> 1) * AS_PLANE;
@@ -173,13 +184,13 @@ __global__ void __launch_bounds__(AS_THREADS)
                     ctx = as_next_ctx<ORDER1>(P, ctx, s[q]);
                 }
 #pragma unroll
-                for (u32 j = 0; j < 2; ++j) {
-                    const u32 q = 2 * half + j;
+                for (u32 j = 0; j < AS_TILE; ++j) {
+                    const u32 q = AS_TILE * half + j;
                     u32 cd = __builtin_amdgcn_alignbit(w1[j], w0[j], 16 * (s[q] & 1));
                     if (s[q] == 15) cd = (cd & 0xFFFFu) | (T[j] << 16);  // X[16] is the total
                     const double x = af_recip((double)T[j]);
-                    *reinterpret_cast<double *>(lds + AS_F1X_BASE + (half * AS_TILE + j) * AS_F1X_SLOT + lane * 8) = x;
-                    *reinterpret_cast<u32_lds *>(lds + AS_F1C_BASE + (half * AS_TILE + j) * AS_F1C_SLOT + lane4) = cd;
+                    *reinterpret_cast<double *>(lds + AS_F1X_BASE + (buf * AS_TILE + j) * AS_F1X_SLOT + lane * 8) = x;
+                    *reinterpret_cast<u32_lds *>(lds + AS_F1C_BASE + (buf * AS_TILE + j) * AS_F1C_SLOT + lane4) = cd;
                 }
                 __syncthreads();
             }
@@ -198,13 +209,23 @@ __global__ void __launch_bounds__(AS_THREADS)
         u32 low = 0, hm = 0xFFFFFFFFu;
         u32 pending = 0;
         for (u32 r = 0; r < n_rounds; ++r) {
-            const u32 buf1 = (r + 1) & 1, buf2 = (r + 1) & 1;  // tile r - 1
+            const u32 buf1 = (AS_NBUF == 2) ? ((r + 1) & 1) : 0, buf2 = buf1;  // tile r - 1
+            double xt[AS_TILE];
+            u32 cdt[AS_TILE];
+            if (AS_NBUF == 1) {  // the whole tile into registers, then the buffers are free for the next one
+#pragma unroll
+                for (u32 j = 0; j < AS_TILE; ++j) {
+                    xt[j] = *reinterpret_cast<const double *>(lds + AS_F1X_BASE + j * AS_F1X_SLOT + lane * 8);
+                    cdt[j] = *reinterpret_cast<const u32_lds *>(lds + AS_F1C_BASE + j * AS_F1C_SLOT + lane * 4);
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (u32 j = 0; j < AS_TILE; ++j) {
                 const u32 i = (r - 1) * AS_TILE + j;
                 if (r > 0 && i < n && !(AS_ABLATE & 2)) {
-                    const double x = *reinterpret_cast<const double *>(lds + AS_F1X_BASE + (buf1 * AS_TILE + j) * AS_F1X_SLOT + lane * 8);
-                    const u32 cd = *reinterpret_cast<const u32_lds *>(lds + AS_F1C_BASE + (buf1 * AS_TILE + j) * AS_F1C_SLOT + lane * 4);
+                    const double x = (AS_NBUF == 1) ? xt[j] : *reinterpret_cast<const double *>(lds + AS_F1X_BASE + (buf1 * AS_TILE + j) * AS_F1X_SLOT + lane * 8);
+                    const u32 cd = (AS_NBUF == 1) ? cdt[j] : *reinterpret_cast<const u32_lds *>(lds + AS_F1C_BASE + (buf1 * AS_TILE + j) * AS_F1C_SLOT + lane * 4);
                     const double rd = (double)(hm - low) + 1.0;
                     const u32 q1 = (u32)(__builtin_fma(rd, (double)(cd & 0xFFFFu), 0.5) * x);
                     const u32 q2m1 = (u32)__builtin_fma(__builtin_fma(rd, (double)(cd >> 16), 0.5), x, -1.0);
@@ -296,12 +317,19 @@ __global__ void __launch_bounds__(AS_THREADS)
         }
     }
     for (u32 r = 0; r < n_rounds; ++r) {
-        const u32 buf2 = r & 1;  // tile r - 2
+        const u32 buf2 = (AS_NBUF == 2) ? (r & 1) : 0;  // tile r - 2
+        uint2 et[AS_TILE];
+        if (AS_NBUF == 1) {
+#pragma unroll
+            for (u32 j = 0; j < AS_TILE; ++j)
+                et[j] = *reinterpret_cast<const uint2 *>(lds + AS_F2_BASE + j * AS_F2_SLOT + lane * 8);
+            __syncthreads();
+        }
 #pragma unroll
         for (u32 j = 0; j < AS_TILE; ++j) {
             const u32 i = (r - 2) * AS_TILE + j;
             if (r > 1 && i < n && !(AS_ABLATE & 4)) {
-                const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_F2_BASE + (buf2 * AS_TILE + j) * AS_F2_SLOT + lane * 8);
+                const uint2 e = (AS_NBUF == 1) ? et[j] : *reinterpret_cast<const uint2 *>(lds + AS_F2_BASE + (buf2 * AS_TILE + j) * AS_F2_SLOT + lane * 8);
                 const u32 k = e.y & 0xFFu, pend = e.y >> 8, top = e.x;
                 // the k E1/E2 steps emit b0, then `pend` copies of !b0, then the other k - 1 bits of top
                 const u32 km1 = (k - 1) & 31;
