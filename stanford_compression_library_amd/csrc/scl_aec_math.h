@@ -52,6 +52,20 @@ __device__ __forceinline__ void af_shrink2(u32 &low, u32 &hm, u32 c, u32 d, doub
     low = low + q1;
 }
 
+// shrink_range for a power-of-two total T = 2^t (static models; tANS-style tables): rng c >> t in integers.  rng c =
+// (rng - 1) c + c is one v_mad_u64_u32 (rng itself may be 2^32), the quotient one v_alignbit; (rng d) >> t can be 2^32
+// (rng = 2^32, d = T) but high' - 1 = low + that - 1 is below 2^32, so arithmetic mod 2^32 is exact.  Seven integer
+// instructions instead of thirteen with six binary64 ones.
+__device__ __forceinline__ void af_shrink_pow2(u32 &low, u32 &hm, u32 c, u32 d, u32 t) {
+    const u32 r1 = hm - low;
+    const u64 p1 = (u64)r1 * c + c;
+    const u64 p2 = (u64)r1 * d + d;
+    const u32 q1 = __builtin_amdgcn_alignbit((u32)(p1 >> 32), (u32)p1, t);
+    const u32 q2 = __builtin_amdgcn_alignbit((u32)(p2 >> 32), (u32)p2, t);
+    hm = low + q2 - 1u;
+    low = low + q1;
+}
+
 // closed-form step counts AND the renormalised interval; true if the literal loops must be used for this symbol.
 // The corner test of af_renorm_counts on the SHIFTED values: ctz(low) + k + m + 1 >= 32 with low != 0 <=> every bit of
 // low leaves, i.e. (low << (k + m)) & 0x7FFFFFFF == 0; for high = hm + 1 != 2^32: (high << (k + m + 1)) mod 2^32 == 0 <=>

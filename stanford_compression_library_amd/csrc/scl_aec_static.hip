@@ -23,6 +23,7 @@
 
 struct AecStaticDev {
     u32 K, T;
+    u32 t;          // log2(T) when T is a power of two (the POW2 kernels), else unused
     u32 size_bits;  // DATA_BLOCK_SIZE_BITS (1..32)
     const u32 *d_freq, *d_cum;
 };
@@ -43,9 +44,13 @@ typedef AnsFwdWriter<AS_THREADS> AsOut;
 typedef AnsBitReader<AS_THREADS, true> AsIn;
 
 // one symbol of the encoder: shrink_range, then the renormalisation loops (:126-150)
-__device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending, u32 c, u32 d, u32 T, double xT,
+template <bool POW2>
+__device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending, u32 c, u32 d, u32 t, double xT,
                                                  AsOut &wr, char *lds) {
-    af_shrink2(low, hm, c, d, xT);
+    if (POW2)
+        af_shrink_pow2(low, hm, c, d, t);
+    else
+        af_shrink2(low, hm, c, d, xT);
     u32 k, m, nlow, nhm;
     const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
     if (__builtin_expect(edge || (k + pending > 32), 0)) {
@@ -88,6 +93,8 @@ __device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending
     }
 }
 
+// POW2: the total is a power of two, shrink_range in integers (af_shrink_pow2)
+template <bool POW2>
 __global__ void __launch_bounds__(AS_THREADS, 4)
     aec_static_encode_kernel(AecStaticDev P, const u8 *__restrict__ sym, u64 sym_stride, const u32 *__restrict__ lens,
                              u32 chunk_len, u64 n_chunks, u8 *__restrict__ out, u64 out_stride,
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             bad = max(bad, s);
             s = (s < P.K) ? s : 0u;
             const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_TAB_BASE + s * 8);
-            as_encode_symbol(low, hm, pending, e.x, e.y, P.T, xT, wr, lds);
+            as_encode_symbol<POW2>(low, hm, pending, e.x, e.y, P.t, xT, wr, lds);
         }
         wr.maybe_flush(lds);  // <= 4 new words per fast-path call on top of <= 15 pending (ring of 32)
     };
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
 }
 
 // LUT = true: total <= 4096, the decoder's search is one byte read by target slot; else a binary search on c
-template <bool LUT>
+template <bool LUT, bool POW2>
 __global__ void __launch_bounds__(AS_THREADS, 4)
     aec_static_decode_kernel(AecStaticDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                              const u64 *__restrict__ bit_off, const u32 *__restrict__ in_nbits, u64 n_chunks,
@@ -216,7 +223,10 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             }
         }
         const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_TAB_BASE + s * 8);
-        af_shrink2(low, hm, e.x, e.y, xT);
+        if (POW2)
+            af_shrink_pow2(low, hm, e.x, e.y, P.t);
+        else
+            af_shrink2(low, hm, e.x, e.y, xT);
         if (last) return s;
         u32 k, m, nlow, nhm;
         const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
@@ -316,6 +326,7 @@ static AecStaticDev aec_static_dev(const scl_aec_model *m) {
     AecStaticDev f;
     f.K = m->dev.K;
     f.T = m->dev.total0;
+    f.t = (f.T & (f.T - 1)) == 0 ? scl_bit_width_u64(f.T) - 1 : 0xFFFFFFFFu;
     f.size_bits = m->dev.size_bits;
     f.d_freq = m->dev.d_freq;
     f.d_cum = m->dev.d_cum;
@@ -326,21 +337,35 @@ void aec_static_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_s
                               u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset,
                               u32 *d_out_nbits, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + AS_THREADS - 1) / AS_THREADS);
-    hipLaunchKernelGGL(aec_static_encode_kernel, dim3(blocks), dim3(AS_THREADS), 0, st, aec_static_dev(m), d_sym,
-                       sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits,
-                       d_status);
+    const AecStaticDev dev = aec_static_dev(m);
+    if (dev.t != 0xFFFFFFFFu)
+        hipLaunchKernelGGL(aec_static_encode_kernel<true>, dim3(blocks), dim3(AS_THREADS), 0, st, dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
+    else
+        hipLaunchKernelGGL(aec_static_encode_kernel<false>, dim3(blocks), dim3(AS_THREADS), 0, st, dev, d_sym, sym_stride,
+                           d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset, d_out_nbits, d_status);
 }
 
 void aec_static_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                               u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + AS_THREADS - 1) / AS_THREADS);
-    if (m->dev.total0 <= 4096)
-        hipLaunchKernelGGL(aec_static_decode_kernel<true>, dim3(blocks), dim3(AS_THREADS), 0, st, aec_static_dev(m),
-                           d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
-                           d_out_lens, d_consumed, d_status);
-    else
-        hipLaunchKernelGGL(aec_static_decode_kernel<false>, dim3(blocks), dim3(AS_THREADS), 0, st,
-                           aec_static_dev(m), d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym,
-                           out_stride, out_cap, d_out_lens, d_consumed, d_status);
+    const AecStaticDev dev = aec_static_dev(m);
+    const bool pow2 = dev.t != 0xFFFFFFFFu;
+#define AS_LAUNCH_DEC(LUT, POW2)                                                                                         \
+    hipLaunchKernelGGL((aec_static_decode_kernel<LUT, POW2>), dim3(blocks), dim3(AS_THREADS), 0, st, dev, d_in,          \
+                       in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,   \
+                       d_consumed, d_status)
+    if (m->dev.total0 <= 4096) {
+        if (pow2)
+            AS_LAUNCH_DEC(true, true);
+        else
+            AS_LAUNCH_DEC(true, false);
+    } else {
+        if (pow2)
+            AS_LAUNCH_DEC(false, true);
+        else
+            AS_LAUNCH_DEC(false, false);
+    }
+#undef AS_LAUNCH_DEC
 }
