@@ -111,7 +111,7 @@ def test_batch_ragged_vs_oracle(name, dev):
         assert np.array_equal(dec2[c, :lens[c]].cpu().numpy(), sym[c, :lens[c]])
 
 
-@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0)])
+@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0), (17, 1), (31, 1), (32, 1), (20, 2)])
 def test_batch_aec_orderk_vs_oracle(K, k, dev):
     """order-k adaptive arithmetic coding with the any-parameter kernels (global-memory / LDS16 / two-level
     models of scl_aec.hip), private model per lane"""
