@@ -591,12 +591,13 @@ static bool aec_use_lds(const scl_aec_model *m, u64 max_symbols) {
     return max_init + max_symbols < 65535 && m->dev.max_total > max_init + max_symbols;
 }
 
+// zero_bytes != 0: the kernels about to run use (and need zero-filled) only that much of it (scl_aec_wide.hip: u16 cells)
 static int aec_prepare_scratch(const scl_aec_model *m, u64 n_chunks, void *d_scratch, u64 scratch_bytes,
-                               hipStream_t st) {
+                               hipStream_t st, u64 zero_bytes = 0) {
     const u64 need = m->dev.cells * n_chunks * sizeof(u32);
     SCL_REQUIRE(need == 0 || (d_scratch && scratch_bytes >= need), "aec: scratch of %llu bytes required, got %llu",
                 (unsigned long long)need, (unsigned long long)scratch_bytes);
-    if (m->dev.kind == SCL_MODEL_ORDERK) SCL_HIP_TRY(hipMemsetAsync(d_scratch, 0, need, st));
+    if (m->dev.kind == SCL_MODEL_ORDERK) SCL_HIP_TRY(hipMemsetAsync(d_scratch, 0, zero_bytes ? zero_bytes : need, st));
     return SCL_OK;
 }
 
@@ -642,13 +643,14 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
+    // order-k on a large alphabet: the same two-level rows in device memory, tuned arithmetic, lookups issued ahead (scl_aec_wide.hip)
+    const bool wide = tuned && aec_wide_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
+                      sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len);
     if (!aec_use_lds(m, chunk_len)) {
-        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st, wide ? aec_wide_scratch_bytes(m, n_chunks) : 0);
         if (rc) return rc;
     }
-    // order-k on a large alphabet: the same device-memory rows, tuned arithmetic, lookups issued ahead (scl_aec_wide.hip)
-    if (tuned && aec_wide_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
-        sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len)) {
+    if (wide) {
         aec_wide_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
                                d_out_nbits, d_status, (u32 *)d_scratch, st);
         SCL_HIP_TRY(hipGetLastError());
@@ -720,12 +722,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
         SCL_HIP_TRY(hipGetLastError());
         return relay.out_end();
     }
+    const bool wide = tuned && aec_wide_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
+                      out_stride >= scl_round_up(out_cap, 4);
     if (!aec_use_lds(m, out_cap)) {
-        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st);
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st, wide ? aec_wide_scratch_bytes(m, n_chunks) : 0);
         if (rc) return rc;
     }
-    if (tuned && aec_wide_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
-        out_stride >= scl_round_up(out_cap, 4)) {
+    if (wide) {
         aec_wide_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                                d_out_lens, d_consumed, d_status, (u32 *)d_scratch, st);
         SCL_HIP_TRY(hipGetLastError());

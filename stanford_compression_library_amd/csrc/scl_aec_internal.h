@@ -39,6 +39,7 @@ int aec_split_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_str
                             u32 *d_status, hipStream_t st);
 // scl_aec_wide.hip: order-k models in the two-level row layout (large alphabets), tuned arithmetic over device-memory rows
 bool aec_wide_ok(const scl_aec_model *m, u64 max_symbols);
+u64 aec_wide_scratch_bytes(const scl_aec_model *m, u64 n_chunks);
 void aec_wide_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
                             u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
                             u32 *d_status, u32 *d_scratch, hipStream_t st);

@@ -34,16 +34,37 @@ struct AecWideDev {
     u64 cells;      // per chunk: ctx_mod * row_cells
 };
 
+// Cells are u16 here (the any-parameter kernels keep u32 cells in the same scratch: these kernels own their zero-filled
+// scratch for one launch and use the first half of it): every count and block total stays below 2^15 (aec_wide_ok), and a
+// group of 16 cells is 32 bytes -- the kernels are bound by the number of bytes their scattered row accesses move.
+#ifndef AW_CELL16
+#define AW_CELL16 1
+#endif
+#if AW_CELL16
+typedef u16 aw_cell;
+#else
+typedef u32 aw_cell;
+#endif
 struct AwRow {  // 16 consecutive cells
     u32 v[16];
 };
-// 64 bytes, 64-byte aligned, as four 16-byte loads issued back to back
-__device__ __forceinline__ AwRow aw_load16(const u32 *p) {
+// 16 cells, aligned to their size, as 16-byte loads issued back to back
+__device__ __forceinline__ AwRow aw_load16(const aw_cell *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
     AwRow r;
+#if AW_CELL16
+    const uint4 a = q[0], b = q[1];
+    const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (u32 j = 0; j < 8; ++j) {
+        r.v[2 * j] = w[j] & 0xFFFFu;
+        r.v[2 * j + 1] = w[j] >> 16;
+    }
+#else
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
     r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w, r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
     r.v[8] = c.x, r.v[9] = c.y, r.v[10] = c.z, r.v[11] = c.w, r.v[12] = d.x, r.v[13] = d.y, r.v[14] = d.z, r.v[15] = d.w;
+#endif
     return r;
 }
 __device__ __forceinline__ u32 aw_next_ctx(const AecWideDev &P, u32 ctx, u32 s) {  // past_k[1:] + [s], :146-151
@@ -61,7 +82,7 @@ __global__ void __launch_bounds__(AW_THREADS)
     if (chunk >= n_chunks) return;
     const u32 n = lens ? lens[chunk] : chunk_len;
     const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
-    u32 *cnt = scratch + chunk * P.cells;
+    aw_cell *cnt = reinterpret_cast<aw_cell *>(scratch) + chunk * P.cells;
     AfWriter wr;
     wr.init(out + chunk * out_stride);
     wr.put(P.size_bits < 32 ? (n & ((1u << P.size_bits) - 1u)) : n, P.size_bits);  // header, :92-99
@@ -164,8 +185,8 @@ __global__ void __launch_bounds__(AW_THREADS)
         T_pv = P.K + tot;
         x_pv = af_recip((double)T_pv);
         // update_model (:143-160): count[s] += 1, block total += 1 (cells hold count - 1)
-        cnt[rb + 16 + s] = fs + 1;
-        cnt[rb + b] = fb + 1;
+        cnt[rb + 16 + s] = (aw_cell)(fs + 1);
+        cnt[rb + b] = (aw_cell)(fb + 1);
         p_ctx = ctx;
         p_s = s;
         ctx = ctx_nx;
@@ -214,7 +235,7 @@ __global__ void __launch_bounds__(AW_THREADS)
         if (status) status[chunk] = st;
         return;
     }
-    u32 *cnt = scratch + chunk * P.cells;
+    aw_cell *cnt = reinterpret_cast<aw_cell *>(scratch) + chunk * P.cells;
     u32 *dst = reinterpret_cast<u32 *>(out_sym + chunk * out_stride);
     u64 used = 32;
     u32 state = rd.get(32);
@@ -262,8 +283,8 @@ __global__ void __launch_bounds__(AW_THREADS)
         const u32 s = 16 * b + w;
         const u32 d = c + 1 + fs;
         // update_model, then the next symbol's block totals: issued now, needed after the arithmetic below
-        cnt[rb + 16 + s] = fs + 1;
-        cnt[rb + b] = fb + 1;
+        cnt[rb + 16 + s] = (aw_cell)(fs + 1);
+        cnt[rb + b] = (aw_cell)(fb + 1);
         ctx = aw_next_ctx(P, ctx, s);
         bt = aw_load16(cnt + (u64)ctx * P.row_cells);
         af_shrink2(low, hm, c, d, xT);
@@ -343,6 +364,9 @@ static AecWideDev aec_wide_dev(const scl_aec_model *m) {
     f.cells = m->dev.cells;
     return f;
 }
+
+// bytes of the scratch these kernels use (and need zero-filled) for n_chunks chunks
+u64 aec_wide_scratch_bytes(const scl_aec_model *m, u64 n_chunks) { return m->dev.cells * n_chunks * sizeof(aw_cell); }
 
 void aec_wide_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
                             u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
