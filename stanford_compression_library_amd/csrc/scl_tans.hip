@@ -12,6 +12,7 @@
 //   dec_sym[x - L], dec_xs[x - L]       = base_decode_step_table[x] = (s, x_shrunk)  RF*M entries
 //   expand_state_num_bits_table[x_shrunk] = NUM_STATE_BITS - bit_width(x_shrunk) is computed with clz.
 // The bit stream is identical to rANS with the same parameters (same layout as scl_rans.hip).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -187,6 +188,13 @@ __global__ void __launch_bounds__(256) tans_decode_kernel(TansDev P, const u8 *_
 // ---- host API -------------------------------------------------------------------------------------------
 #define TANS_LDS_BUDGET (64u * 1024u)
 
+// SCL_TANS_KERNELS=table in the environment: models whose tables fit LDS run the lookup-table kernels
+// (scl_tans_fast.hip) instead of the table-free rANS kernels (tests run every tANS case both ways)
+static bool tans_table_kernels_forced() {
+    const char *e = getenv("SCL_TANS_KERNELS");
+    return e && e[0] == 't';
+}
+
 // builds base_encode_step_table / base_decode_step_table / the per-symbol tables on the device, once
 static int tans_ensure_tables(const scl_tans_model *cm) {
     scl_tans_model *m = const_cast<scl_tans_model *>(cm);
@@ -241,8 +249,11 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
                 (unsigned long long)M);
     const u64 L = range_factor * M;
     // companion rANS model (same stream, no tables): see scl_tans_model::rans
+    // (round 3: also for tables that fit LDS -- on this machine the table-free kernels are the faster way to write the
+    // same stream, 0.55 / 0.56 ms against 0.72 / 0.58 ms per GiB for the LDS-table kernels at RANGE_FACTOR = 1, whose
+    // per-symbol gathers keep the LDS pipe 82 % busy; SCL_TANS_KERNELS=table keeps the lookup-table kernels in charge)
     scl_rans_model *rans = nullptr;
-    if (L > 8192 && L <= (1ull << 30)) {
+    if (L <= (1ull << 30) && K <= 256) {
         if (scl_rans_model_create(h_freq, K, range_factor, 1, size_bits, &rans) == SCL_OK && rans && !rans->fast) {
             scl_rans_model_destroy(rans);
             rans = nullptr;
@@ -298,8 +309,9 @@ extern "C" int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_
     // A model with a companion rANS handle is served by the table-free kernels: its 3 x L-entry tables (768 MiB at
     // 2^26 entries) are only built if somebody asks for them (scl_tans_model_tables, or rows the tuned kernels
     // cannot take) -- tans_ensure_tables.
-    int rc = (m->tables && !m->rans) ? tans_ensure_tables(m) : SCL_OK;
-    if (rc == SCL_OK && m->tables && !m->rans && K <= 256) rc = tans_fast_build_tables(m, h_freq, cum);
+    const bool small = m->tables && L <= 8192;  // LDS-sized tables are built at once (the tuned table kernels need them)
+    int rc = (m->tables && (!m->rans || small)) ? tans_ensure_tables(m) : SCL_OK;
+    if (rc == SCL_OK && m->tables && (!m->rans || small) && K <= 256) rc = tans_fast_build_tables(m, h_freq, cum);
     if (rc != SCL_OK) {
         scl_tans_model_destroy(m);
         return rc;
@@ -368,21 +380,24 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
     SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "tans_encode_batch: d_out must be 16-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     const bool tuned = !scl_force_generic();
+    const bool table_first = m->fast && tans_table_kernels_forced();  // else the table-free kernels when the model has them
     RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid for the tuned kernels
     if ((tuned || !m->tables) && (m->fast || m->rans))
         if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, (hipStream_t)stream)) return rc_r;
-    if (tuned && m->fast && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
-        out_stride >= scl_tans_slot_bytes(m, chunk_len)) {
-        tans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
-                                d_out_nbits, d_status, (hipStream_t)stream);
+    const bool rows_ok = ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0;
+    const bool fast_ok = tuned && m->fast && rows_ok && out_stride >= scl_tans_slot_bytes(m, chunk_len);
+    // same stream from the table-free rANS kernels (32-bit slot offsets per workgroup)
+    const bool rans_ok = (tuned || !m->tables) && m->rans && rows_ok &&
+                         out_stride >= scl_rans_slot_bytes(m->rans, chunk_len) && out_stride < (1ull << 24);
+    if (rans_ok && !(table_first && fast_ok)) {
+        rans_fast_encode_launch(m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
+                                d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
-    if ((tuned || !m->tables) && m->rans && ((uintptr_t)d_sym & 15) == 0 && (sym_stride & 15) == 0 &&
-        out_stride >= scl_rans_slot_bytes(m->rans, chunk_len) &&
-        out_stride < (1ull << 24)) {  // same stream from the table-free rANS kernels (32-bit slot offsets per workgroup)
-        rans_fast_encode_launch(m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
-                                d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
+    if (fast_ok) {
+        tans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                                d_out_nbits, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
     }
@@ -413,15 +428,18 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
     RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
     if ((tuned || !m->tables) && (m->fast || m->rans) && ((uintptr_t)d_in & 15) == 0)
         if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, (hipStream_t)stream)) return rc_r;
-    if (tuned && m->fast && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0) {
-        tans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+    const bool table_first = m->fast && tans_table_kernels_forced();
+    const bool bufs_ok = ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0;
+    const bool fast_ok = tuned && m->fast && bufs_ok;
+    const bool rans_ok = (tuned || !m->tables) && m->rans && bufs_ok;
+    if (rans_ok && !(table_first && fast_ok)) {
+        rans_fast_decode_launch(m->rans, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return relay.out_end();
     }
-    if ((tuned || !m->tables) && m->rans && ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out_sym & 15) == 0 &&
-        (out_stride & 15) == 0) {
-        rans_fast_decode_launch(m->rans, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
+    if (fast_ok) {
+        tans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return relay.out_end();

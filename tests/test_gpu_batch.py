@@ -421,6 +421,21 @@ def test_rans_tests_with_slot_writer_forced():
     assert " passed" in r.stdout
 
 
+def test_tans_tests_with_table_kernels_forced():
+    """tANS models whose tables fit LDS run the table-free rANS kernels by default (same stream, faster here); every tANS
+    test of the suite once more with SCL_TANS_KERNELS=table, i.e. on the lookup-table kernels of scl_tans_fast.hip"""
+    import subprocess, sys
+    env = dict(os.environ, SCL_TANS_KERNELS="table")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_batch.py"),
+                        os.path.join(here, "test_gpu_goldens.py"), os.path.join(here, "test_gpu_guard_bands.py"),
+                        os.path.join(here, "test_gpu_stream_goldens.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "tans and not table_kernels_forced and not slot_writer", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def _check_sample_against_oracle(enc, sample, o_enc, sym_rows):
     offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
     for c, row in zip(sample, sym_rows):
