@@ -28,6 +28,7 @@
 //            (count - 1) -- so that a lookup is two 64-byte reads issued together (ONE memory round trip; these
 //            tables live in HBM/L2 and the kernel is bound by that latency), an update two stores, and the
 //            decoder's search two dependent 64-byte reads, instead of a scan of the whole row.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -591,6 +592,13 @@ static bool aec_use_lds(const scl_aec_model *m, u64 max_symbols) {
     return max_init + max_symbols < 65535 && m->dev.max_total > max_init + max_symbols;
 }
 
+// SCL_AEC_WIDE=dense in the environment keeps the two-level-row kernels of scl_aec_wide.hip in charge of order-k models on
+// large alphabets (tests run both; the default is scl_aec_sparse.hip)
+static bool aec_wide_dense_forced() {
+    const char *e = getenv("SCL_AEC_WIDE");
+    return e && e[0] == 'd';
+}
+
 // zero_bytes != 0: the kernels about to run use (and need zero-filled) only that much of it (scl_aec_wide.hip: u16 cells)
 static int aec_prepare_scratch(const scl_aec_model *m, u64 n_chunks, void *d_scratch, u64 scratch_bytes,
                                hipStream_t st, u64 zero_bytes = 0) {
@@ -647,8 +655,17 @@ extern "C" int scl_aec_encode_batch(const scl_aec_model *m, const uint8_t *d_sym
     const bool wide = tuned && aec_wide_ok(m, chunk_len) && ((uintptr_t)d_sym & 3) == 0 && (sym_stride & 3) == 0 &&
                       sym_stride >= scl_round_up(chunk_len, 4) && out_stride >= scl_aec_slot_bytes(m, chunk_len);
     if (!aec_use_lds(m, chunk_len)) {
-        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st, wide ? aec_wide_scratch_bytes(m, n_chunks) : 0);
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st,
+                                     wide ? (aec_wide_dense_forced() ? aec_wide_scratch_bytes(m, n_chunks)
+                                                                     : aec_sparse_zero_bytes(m, n_chunks))
+                                          : 0);
         if (rc) return rc;
+    }
+    if (wide && !aec_wide_dense_forced()) {  // one table line per symbol while a context is young (scl_aec_sparse.hip)
+        aec_sparse_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                                 d_out_nbits, d_status, (u32 *)d_scratch, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return SCL_OK;
     }
     if (wide) {
         aec_wide_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
@@ -725,8 +742,17 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     const bool wide = tuned && aec_wide_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
                       out_stride >= scl_round_up(out_cap, 4);
     if (!aec_use_lds(m, out_cap)) {
-        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st, wide ? aec_wide_scratch_bytes(m, n_chunks) : 0);
+        int rc = aec_prepare_scratch(m, n_chunks, d_scratch, scratch_bytes, st,
+                                     wide ? (aec_wide_dense_forced() ? aec_wide_scratch_bytes(m, n_chunks)
+                                                                     : aec_sparse_zero_bytes(m, n_chunks))
+                                          : 0);
         if (rc) return rc;
+    }
+    if (wide && !aec_wide_dense_forced()) {
+        aec_sparse_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                                 d_out_lens, d_consumed, d_status, (u32 *)d_scratch, st);
+        SCL_HIP_TRY(hipGetLastError());
+        return relay.out_end();
     }
     if (wide) {
         aec_wide_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,

@@ -46,6 +46,15 @@ void aec_wide_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_str
 void aec_wide_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
                             const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, u32 *d_scratch, hipStream_t st);
+// scl_aec_sparse.hip: the same models with one 64-byte line per context (the symbols seen in it) until it has been seen 28
+// times, then its dense row: one table piece read and written per symbol instead of two
+u64 aec_sparse_zero_bytes(const scl_aec_model *m, u64 n_chunks);
+void aec_sparse_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,
+                              u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_out_bit_offset, u32 *d_out_nbits,
+                              u32 *d_status, u32 *d_scratch, hipStream_t st);
+void aec_sparse_decode_launch(const scl_aec_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_offset,
+                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
+                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, u32 *d_scratch, hipStream_t st);
 // scl_aec_static.hip
 bool aec_static_ok(const scl_aec_model *m);
 void aec_static_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,

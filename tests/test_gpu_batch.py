@@ -132,6 +132,63 @@ def test_batch_aec_orderk_vs_oracle(K, k, dev):
     assert np.array_equal(dec.cpu().numpy(), sym) and np.array_equal(used.cpu().numpy(), nbits)
 
 
+@pytest.mark.parametrize("K,k", [(32, 1), (256, 1), (40, 2), (255, 1), (100, 1)])
+def test_batch_aec_large_alphabet_line_to_row_transitions(K, k, dev):
+    """scl_aec_sparse.hip keeps a context in one 64-byte line (the symbols seen in it) for its first 28 symbols and moves
+    it to its dense row with the 29th: runs of one symbol (the context repeats while its line is still in flight: the
+    patch path, also across the move), a few hot contexts that cross the boundary early and many cold ones, symbol
+    K - 1, chunks that end exactly on the 28th / 29th / 30th symbol of a context.  Streams, symbols and consumed bits
+    against the oracle."""
+    rng = np.random.default_rng(900 + K + k)
+    model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
+    assert model.fast_path(4096)
+    cap = 4096
+    rows = []
+    hot = rng.choice(K, 3, replace=False)
+    for c in range(24):
+        kind = c % 4
+        if kind == 0:    # runs: the same symbol 1..70 times in a row
+            x = np.concatenate([np.full(int(rng.integers(1, 71)), int(rng.integers(0, K))) for _ in range(200)])
+        elif kind == 1:  # three hot symbols (hot contexts) with rare excursions over the whole alphabet
+            x = np.where(rng.random(cap) < 0.9, rng.choice(hot, cap), rng.integers(0, K, cap))
+        elif kind == 2:  # uniform: every context stays cold for K = 256
+            x = rng.integers(0, K, cap)
+        else:            # one symbol only, incl. the last of the alphabet
+            x = np.full(cap, K - 1 if c % 8 == 3 else 0)
+        rows.append(np.resize(x, cap))
+    sym = np.stack(rows).astype(np.uint8)
+    lens = np.array([27, 28, 29, 30, 31, 57, 58, 59] + [int(v) for v in rng.integers(0, cap + 1, 15)] + [cap], dtype=np.int32)
+    sym[:8] = sym[3]  # the single-symbol row: its one context takes exactly lens[i] symbols
+    enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
+    dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0 and int(status.abs().sum()) == 0
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    dec, used = dec.cpu().numpy(), used.cpu().numpy()
+    assert np.array_equal(dlens.cpu().numpy(), lens)
+    for c in range(lens.size):
+        rb, rn = orc.aec_encode(sym[c, :lens[c]], orc.MODEL_ORDERK, K, k=k)
+        assert int(nbits[c]) == rn, f"chunk {c}: {nbits[c]} bits vs oracle {rn}"
+        assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
+        assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        if lens[c] > 0:
+            assert used[c] == orc.aec_decode(rb, rn, orc.MODEL_ORDERK, K, k=k)[1], f"chunk {c}"
+
+
+def test_large_alphabet_order_k_tests_with_dense_rows_forced():
+    """order-k models on 32..256 symbols run scl_aec_sparse.hip by default; the same tests once more with SCL_AEC_WIDE=dense,
+    i.e. on the two-level-row kernels of scl_aec_wide.hip"""
+    import subprocess, sys
+    env = dict(os.environ, SCL_AEC_WIDE="dense")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_batch.py"),
+                        os.path.join(here, "test_gpu_goldens.py"), os.path.join(here, "test_gpu_guard_bands.py"), "-q", "-m",
+                        "gpu", "-x", "-k", "(orderk or order1 or large_alphabet or aec or config4) and not forced and not "
+                        "full_occupancy", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 AEC_FAST_CASES = [("orderk", 16, 1), ("orderk", 4, 1), ("orderk", 2, 1), ("orderk", 3, 2), ("orderk", 2, 3),
                   ("orderk", 5, 0), ("orderk", 16, 0), ("orderk", 7, 1), ("iid", 2, 0), ("iid", 11, 0), ("iid", 16, 0),
                   ("iid", 17, 0), ("iid", 100, 0), ("iid", 255, 0), ("iid", 256, 0)]
