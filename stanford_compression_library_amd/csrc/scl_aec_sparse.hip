@@ -14,8 +14,8 @@
 //
 // Layout (inside the scratch of scl_aec_scratch_bytes, which is sized for u32 dense rows):
 //   [n_chunks x ctx_mod lines of 64 bytes, zero-filled before the launch]
-//   [n_chunks x ctx_mod dense rows of row_cells u16 cells, the layout of scl_aec_wide.hip; a row is zeroed when its context
-//    moves into it, so the launch zero-fills 16 KiB per chunk instead of 136]
+//   [n_chunks x ctx_mod dense rows of row_cells u16 cells, the layout of scl_aec_wide.hip; a row is written whole when its
+//    context moves into it, so the launch zero-fills 16 KiB per chunk instead of 136]
 // A line is {u32 n, 28 x u16 entry, 4 bytes unused}: the first n entries hold symbol + 1 in arrival order, 0 = empty.
 //   count of symbols < s   = n - #{entries > s}
 //   count of symbol s      = #{entries > s} - #{entries > s + 1}          (+ 1 each: the model starts from all ones)
