@@ -396,9 +396,6 @@ __global__ void __launch_bounds__(AP_THREADS)
                 u = ok ? u : u + bit;
             }
             s = tgt - u;
-            const u32 g0 = ap_count_gt(L, s), g1 = ap_count_gt(L, s + 1);
-            c = s + cnt - g0;
-            f = 1 + g0 - g1;
             if (cnt < AP_MAX) {
                 reinterpret_cast<u16 *>(line)[2 + cnt] = (u16)(s + 1);
                 line[0] = cnt + 1;
@@ -406,10 +403,19 @@ __global__ void __launch_bounds__(AP_THREADS)
                 ap_move_to_dense(L, line, row, P.row_cells, 0u, s + 1, stage, threadIdx.x);
             }
         }
-        const double xT = af_recip((double)T);
-        // the next symbol's line: issued now, needed after the arithmetic below
+        // the symbol is known and counted: the next symbol's line is issued NOW (it is the one access this lane waits for),
+        // (c, f) of this symbol and the arithmetic come out of the line in hand while it travels
+        const ApLine Lc = L;
+        const bool was_dense = Lc.w[0] == AP_DENSE;
         ctx = ap_next_ctx(P, ctx, s);
         L = ap_load_line(lines + 16ull * ctx);
+        if (!was_dense) {
+            const u32 cnt = Lc.w[0];
+            const u32 g0 = ap_count_gt(Lc, s), g1 = ap_count_gt(Lc, s + 1);
+            c = s + cnt - g0;
+            f = 1 + g0 - g1;
+        }
+        const double xT = af_recip((double)T);
         af_shrink2(low, hm, c, c + f, xT);
         // ---- symbol out ----
         oword |= s << (8 * (i & 3));
