@@ -126,7 +126,10 @@ int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_in, uint64_t
  * Lookup tables have RANGE_FACTOR * M entries.  Up to 8192 entries they sit in LDS (tuned kernels); up to 2^26 they
  * are built in device memory; beyond that (the reference's inherited default RANGE_FACTOR = 2^16 with M = 4096 asks
  * for 2^28) no table is built and the model runs on the table-free rANS kernels, which write the same stream --
- * scl_tans_model_tables then fails and the batch entry points need 16-byte aligned rows and slots. */
+ * scl_tans_model_tables then fails and the batch entry points need 16-byte aligned rows and slots.
+ * Since round 3 the table-free kernels are also the DEFAULT for LDS-sized tables wherever they apply (they are the faster
+ * way to write the same stream on this machine); SCL_TANS_KERNELS=table in the environment keeps the lookup-table
+ * kernels in charge.  scl_tans_model_tables exports the tables either way. */
 typedef struct scl_tans_model scl_tans_model;
 
 int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_factor,
