@@ -35,7 +35,7 @@
 #define AP_DENSE 0xFFFFu     // header of a context that lives in its dense row
 
 struct AecSparseDev {
-    u32 K;          // alphabet size 32..256
+    u32 K;          // alphabet size 17..256
     u32 k;          // order 0..3
     u32 ctx_mod;    // K^k
     u32 row_cells;  // 16 + 16 * ceil(K / 16)
@@ -489,7 +489,7 @@ static AecSparseDev aec_sparse_dev(const scl_aec_model *m, u64 n_chunks) {
 
 // bytes at the front of the scratch that must be zero before a launch (the lines); lines + dense rows never need more than
 // the u32 dense rows scl_aec_scratch_bytes is sized for (64 + 2 row_cells <= 4 row_cells for row_cells >= 32, i.e. every
-// alphabet of 32 symbols and more)
+// alphabet these kernels serve)
 u64 aec_sparse_zero_bytes(const scl_aec_model *m, u64 n_chunks) { return 64ull * m->dev.ctx_mod * n_chunks; }
 
 void aec_sparse_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens, u32 chunk_len,

@@ -5,7 +5,7 @@
 //   ArithmeticDecoder.decode_step_core / decode_block                               :177-201, :203-287
 //   AdaptiveOrderKFreqModel                          scl/compressors/probability_models.py:95-160
 //
-// Served models (aec_wide_ok): AdaptiveOrderKFreqModel in the two-level row layout of scl_aec.hip (alphabet 32..256, more
+// Served models (aec_wide_ok): AdaptiveOrderKFreqModel in the two-level row layout of scl_aec.hip (alphabet 17..256, more
 // than 256 cells per chunk: 16 block totals + counts in blocks of 16, all stored as count - 1 in zero-filled scratch),
 // PRECISION = 32, row totals that stay below 2^15 and below the model's rescale threshold for the whole chunk.
 //
@@ -26,7 +26,7 @@
 #define AW_THREADS 256
 
 struct AecWideDev {
-    u32 K;          // alphabet size 32..256
+    u32 K;          // alphabet size 17..256
     u32 k;          // order 0..3
     u32 ctx_mod;    // K^k
     u32 row_cells;  // 16 + 16 * ceil(K / 16)
