@@ -23,8 +23,8 @@
 // Model state lives in caller-provided device scratch, one private region per chunk:
 //   IID    : K   u32 counts, initialised by the lane from the initial frequencies
 //   ORDERK : K^(k+1) u32 cells holding (count - 1); the host zero-fills the scratch (= all-ones counts,
-//            probability_models.py:110) with one hipMemsetAsync before the launch.  Alphabets of 17 symbols and
-//            more store every row in two levels -- 16 block totals, then the counts in blocks of 16, all as
+//            probability_models.py:110) with one hipMemsetAsync before the launch.  Models with more than 256 cells
+//            store every row in two levels -- 16 block totals, then the counts in blocks of 16, all as
 //            (count - 1) -- so that a lookup is two 64-byte reads issued together (ONE memory round trip; these
 //            tables live in HBM/L2 and the kernel is bound by that latency), an update two stores, and the
 //            decoder's search two dependent 64-byte reads, instead of a scan of the whole row.
@@ -506,7 +506,7 @@ extern "C" int scl_aec_model_create(int model_kind, const uint32_t *h_freq_init,
             return SCL_E_PARAM;
         }
         m->dev.cells = cells;
-        if (K >= 17 && K <= 256 && cells > AEC_LDS_CELLS) {  // two-level rows: 16 block totals + counts in blocks of 16
+        if (K <= 256 && cells > AEC_LDS_CELLS) {  // two-level rows: 16 block totals + counts in blocks of 16
             m->dev.fenwick = 1;
             m->dev.row_cells = 16 + 16 * ((K + 15) / 16);
             m->dev.cells = m->dev.ctx_mod * m->dev.row_cells;

@@ -111,7 +111,7 @@ def test_batch_ragged_vs_oracle(name, dev):
         assert np.array_equal(dec2[c, :lens[c]].cpu().numpy(), sym[c, :lens[c]])
 
 
-@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0), (17, 1), (31, 1), (32, 1), (20, 2)])
+@pytest.mark.parametrize("K,k", [(4, 1), (16, 1), (3, 2), (256, 1), (5, 0), (100, 1), (40, 2), (33, 1), (256, 0), (17, 1), (31, 1), (32, 1), (20, 2), (5, 3), (16, 2), (7, 2)])
 def test_batch_aec_orderk_vs_oracle(K, k, dev):
     """order-k adaptive arithmetic coding with the any-parameter kernels (global-memory / LDS16 / two-level
     models of scl_aec.hip), private model per lane"""
@@ -132,7 +132,7 @@ def test_batch_aec_orderk_vs_oracle(K, k, dev):
     assert np.array_equal(dec.cpu().numpy(), sym) and np.array_equal(used.cpu().numpy(), nbits)
 
 
-@pytest.mark.parametrize("K,k", [(32, 1), (256, 1), (40, 2), (255, 1), (100, 1), (17, 1), (20, 2)])
+@pytest.mark.parametrize("K,k", [(32, 1), (256, 1), (40, 2), (255, 1), (100, 1), (17, 1), (20, 2), (5, 3), (16, 2)])
 def test_batch_aec_large_alphabet_line_to_row_transitions(K, k, dev):
     """scl_aec_sparse.hip keeps a context in one 64-byte line (the symbols seen in it) for its first 28 symbols and moves
     it to its dense row with the 29th: runs of one symbol (the context repeats while its line is still in flight: the
