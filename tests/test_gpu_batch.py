@@ -726,7 +726,7 @@ def test_symbol_range_check_boundaries(K, dev):
 def test_random_arithmetic_models_vs_oracle(seed, dev):
     """Differential test of the three tuned arithmetic-coder kernel families on random models: static tables
     (any total up to 2^16), adaptive i.i.d. models with random initial counts (alphabets 2..256) and order-k models
-    (K^k <= 16 contexts); 24 ragged chunks each, streams and consumed-bit counts against the oracle.
+    (K^k <= 16 contexts in LDS, more than 256 cells in device-memory lines / rows); 24 ragged chunks each, streams and consumed-bit counts against the oracle.
     SCL_RANDOM_SEEDS=300 turns this (and the ANS / range twin above) into a campaign."""
     rng = np.random.default_rng(40000 + seed)
     cap = 400
@@ -751,7 +751,9 @@ def test_random_arithmetic_models_vs_oracle(seed, dev):
         o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_IID, K, f_init=f, size_bits=sb)
         p = rng.dirichlet(np.full(K, 0.3))
     else:
-        K, k = [(2, 1), (2, 3), (3, 2), (4, 2), (7, 1), (16, 1), (13, 1), (16, 0), (4, 1)][int(rng.integers(0, 9))]
+        combos = [(2, 1), (2, 3), (3, 2), (4, 2), (7, 1), (16, 1), (13, 1), (16, 0), (4, 1),
+                  (7, 2), (5, 3), (20, 1), (40, 1), (16, 2), (200, 1)]  # the last six: one line per context, then dense rows
+        K, k = combos[int(rng.integers(0, len(combos)))]
         model = models.AecModel(2, None, K, k, 1 << 30, 32, sb)
         o_enc = lambda s: orc.aec_encode(s, orc.MODEL_ORDERK, K, k=k, size_bits=sb)
         o_dec = lambda p, nb: orc.aec_decode(p, nb, orc.MODEL_ORDERK, K, k=k, size_bits=sb)
