@@ -16,22 +16,27 @@
 //   [n_chunks x ctx_mod lines of 64 bytes, zero-filled before the launch]
 //   [n_chunks x ctx_mod dense rows of row_cells u16 cells, the layout of scl_aec_wide.hip; a row is written whole when its
 //    context moves into it, so the launch zero-fills 16 KiB per chunk instead of 136]
-// A line is {u32 n, 28 x u16 entry, 4 bytes unused}: the first n entries hold symbol + 1 in arrival order, 0 = empty.
+// A line is {u32 n, up to 30 x u16 entry}: the first n entries hold symbol + 1 in arrival order, 0 = empty (the
+// encoder uses all 30, the decoder 28: AP_WORDS_ENC / AP_WORDS_DEC below).
 //   count of symbols < s   = n - #{entries > s}
 //   count of symbol s      = #{entries > s} - #{entries > s + 1}          (+ 1 each: the model starts from all ones)
 //   row total              = K + n
-// (#{entries > v} for all 28 at once: 14 x three packed-u16 instructions).  Counting a symbol appends one entry: one
-// 2-byte store and the 4-byte header, same line.  The 29th symbol of a context moves it to its dense row for good (the row
+// (#{entries > v} for all of them at once: three packed-u16 instructions per word).  Counting a symbol appends one entry: one
+// 2-byte store and the 4-byte header, same line.  The symbol that no longer fits moves the context to its dense row for good (the row
 // is built in LDS and written out whole, header 0xFFFF); from then on it costs what scl_aec_wide.hip costs -- and a wave
 // pays that whenever one of its 64 chunks is in such a context.
 // The decoder has no order in the list to search by: it bisects.  With u = target - s, "s + (symbols below s) <= target"
-// reads #{entries <= target - u} - (28 - n) <= u, u in 0..n: five steps of one packed count each.
+// reads (symbols below target - u) <= u, u in 0..n: five steps of one packed count each.
 #include "scl_aec_internal.h"
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
 
 #define AP_THREADS 64       // one wave per workgroup: the staging area below is 17 KiB, nine workgroups fit a CU
-#define AP_MAX 28            // entries per line
+// words of entries per line (two u16 entries each; 15 = the whole line but its header).  Measured on one box: the encoder
+// gains 2 % from the 15th word (fewer contexts outgrow their line), the decoder loses 6 % to it -- each kernel owns its
+// lines, so each takes its own value.
+#define AP_WORDS_ENC 15
+#define AP_WORDS_DEC 14
 #define AP_DENSE 0xFFFFu     // header of a context that lives in its dense row
 
 struct AecSparseDev {
@@ -44,7 +49,7 @@ struct AecSparseDev {
 };
 
 struct ApLine {
-    u32 w[16];  // w[0] = n or AP_DENSE; w[1..14] = entries, two per word
+    u32 w[16];  // w[0] = n or AP_DENSE; w[1..15] = entries, two per word
 };
 __device__ __forceinline__ ApLine ap_load_line(const u32 *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -54,7 +59,8 @@ __device__ __forceinline__ ApLine ap_load_line(const u32 *p) {
     L.w[8] = c.x, L.w[9] = c.y, L.w[10] = c.z, L.w[11] = c.w, L.w[12] = d.x, L.w[13] = d.y, L.w[14] = d.z, L.w[15] = d.w;
     return L;
 }
-// #{entries > v} over all 28 (empty entries are 0 and never count); v < 2^15
+// #{entries > v} over all 2 WORDS entries (empty entries are 0 and never count); v < 2^15
+template <u32 WORDS>
 __device__ __forceinline__ u32 ap_count_gt(const ApLine &L, u32 v) {
     const u32 vp = v | (v << 16);
     u32 a0 = 0, a1 = 0;
@@ -63,6 +69,7 @@ __device__ __forceinline__ u32 ap_count_gt(const ApLine &L, u32 v) {
         a0 = af_pk_count_gt(a0, vp, L.w[j]);
         a1 = af_pk_count_gt(a1, vp, L.w[j + 1]);
     }
+    if (WORDS == 15) a0 = af_pk_count_gt(a0, vp, L.w[15]);
     const u32 a = af_pk_add(a0, a1);  // minus the count, per half
     return (u32)(-((int32_t)(a << 16) >> 16) - ((int32_t)a >> 16));
 }
@@ -89,7 +96,7 @@ __device__ __forceinline__ ApRow16 ap_load16(const u16 *p) {
     return r;
 }
 // The context leaves its line: its dense row (u16 cells: 16 block totals, then the counts) is built in LDS -- a byte per
-// cell, every count is at most 29 here -- and written out whole with plain 16-byte stores: no atomics on device memory, so
+// cell, every count is at most 32 here -- and written out whole with plain 16-byte stores: no atomics on device memory, so
 // this lane's later plain loads of the row see it without any fence (the row has never been read in this launch, and
 // plain stores followed by plain loads of one lane are ordered).  `extra0` / `extra1` (symbol + 1, 0 = none) are counted
 // on top of what the line holds.  LDS image: piece p (cells 16 p .. 16 p + 15) of lane t at [p][t].
@@ -98,6 +105,7 @@ __device__ __forceinline__ void ap_stage_count(char *stage, u32 lane, u32 cell) 
     u32 *wp = reinterpret_cast<u32 *>(stage + (cell >> 4) * (AP_THREADS * 16) + lane * 16 + (cell & 12u));
     __hip_atomic_fetch_add(wp, 1u << (8 * (cell & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+template <u32 WORDS>
 __device__ __forceinline__ void ap_move_to_dense(const ApLine &L, u32 *line, u16 *row, u32 row_cells, u32 extra0, u32 extra1,
                                                  char *stage, u32 lane) {
     const u32 pieces = row_cells >> 4;
@@ -110,7 +118,7 @@ __device__ __forceinline__ void ap_move_to_dense(const ApLine &L, u32 *line, u16
         }
     };
 #pragma unroll
-    for (u32 j = 1; j <= 14; ++j) {
+    for (u32 j = 1; j <= WORDS; ++j) {
         count(L.w[j] & 0xFFFFu);
         count(L.w[j] >> 16);
     }
@@ -252,7 +260,7 @@ __global__ void __launch_bounds__(AP_THREADS)
         const bool same = p_ctx == ctx;  // symbol i - 1 had this context: its entry is missing from L
         const u32 cnt = L.w[0] + (same ? 1u : 0u);  // entries the context has (line not dense), this symbol not among them
         u32 c, f, T;
-        if (__builtin_expect(L.w[0] == AP_DENSE || cnt > AP_MAX, 0)) {
+        if (__builtin_expect(L.w[0] == AP_DENSE || cnt > (2 * AP_WORDS_ENC), 0)) {
             // dense -- when the line was read, or since the previous symbol (whose move the line in hand has not seen):
             // everything counted so far is in the row, read now
             const ApCft r = ap_dense_lookup(row, P.K, s);
@@ -260,16 +268,16 @@ __global__ void __launch_bounds__(AP_THREADS)
             row[16 + s] = (u16)r.f;  // plain stores (visible to this lane's later loads), cells hold count - 1
             row[s >> 4] = (u16)(r.fb + 1);
         } else {
-            const u32 g0 = ap_count_gt(L, s) + ((same && p_s + 1 > s) ? 1u : 0u);
-            const u32 g1 = ap_count_gt(L, s + 1) + ((same && p_s + 1 > s + 1) ? 1u : 0u);
+            const u32 g0 = ap_count_gt<AP_WORDS_ENC>(L, s) + ((same && p_s + 1 > s) ? 1u : 0u);
+            const u32 g1 = ap_count_gt<AP_WORDS_ENC>(L, s + 1) + ((same && p_s + 1 > s + 1) ? 1u : 0u);
             c = s + cnt - g0;
             f = 1 + g0 - g1;
             T = P.K + cnt;
-            if (cnt < AP_MAX) {
+            if (cnt < (2 * AP_WORDS_ENC)) {
                 reinterpret_cast<u16 *>(line)[2 + cnt] = (u16)(s + 1);
                 line[0] = cnt + 1;
-            } else {  // the 29th symbol of this context: the line (and what is missing from it) goes into the dense row
-                ap_move_to_dense(L, line, row, P.row_cells, same ? p_s + 1 : 0u, s + 1, stage, threadIdx.x);
+            } else {  // the line is full: it (and what is missing from it) goes into the dense row with this symbol
+                ap_move_to_dense<AP_WORDS_ENC>(L, line, row, P.row_cells, same ? p_s + 1 : 0u, s + 1, stage, threadIdx.x);
             }
         }
         c_pv = c;
@@ -392,15 +400,15 @@ __global__ void __launch_bounds__(AP_THREADS)
                 // is u + bit - 1 still too small?  then the answer is at least u + bit
                 const u32 t = u + bit - 1;
                 const u32 v = tgt - min(t, tgt);  // candidate symbol (0 when t runs past tgt: then the test passes)
-                const bool ok = (cnt - ap_count_gt(L, v)) <= t;
+                const bool ok = (cnt - ap_count_gt<AP_WORDS_DEC>(L, v)) <= t;
                 u = ok ? u : u + bit;
             }
             s = tgt - u;
-            if (cnt < AP_MAX) {
+            if (cnt < (2 * AP_WORDS_DEC)) {
                 reinterpret_cast<u16 *>(line)[2 + cnt] = (u16)(s + 1);
                 line[0] = cnt + 1;
-            } else {  // the 29th symbol of this context: the line goes into the dense row
-                ap_move_to_dense(L, line, row, P.row_cells, 0u, s + 1, stage, threadIdx.x);
+            } else {  // the line is full: it goes into the dense row with this symbol
+                ap_move_to_dense<AP_WORDS_DEC>(L, line, row, P.row_cells, 0u, s + 1, stage, threadIdx.x);
             }
         }
         // the symbol is known and counted: the next symbol's line is issued NOW (it is the one access this lane waits for),
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(AP_THREADS)
         L = ap_load_line(lines + 16ull * ctx);
         if (!was_dense) {
             const u32 cnt = Lc.w[0];
-            const u32 g0 = ap_count_gt(Lc, s), g1 = ap_count_gt(Lc, s + 1);
+            const u32 g0 = ap_count_gt<AP_WORDS_DEC>(Lc, s), g1 = ap_count_gt<AP_WORDS_DEC>(Lc, s + 1);
             c = s + cnt - g0;
             f = 1 + g0 - g1;
         }

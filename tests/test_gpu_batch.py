@@ -134,10 +134,10 @@ def test_batch_aec_orderk_vs_oracle(K, k, dev):
 
 @pytest.mark.parametrize("K,k", [(32, 1), (256, 1), (40, 2), (255, 1), (100, 1), (17, 1), (20, 2), (5, 3), (16, 2)])
 def test_batch_aec_large_alphabet_line_to_row_transitions(K, k, dev):
-    """scl_aec_sparse.hip keeps a context in one 64-byte line (the symbols seen in it) for its first 28 symbols and moves
-    it to its dense row with the 29th: runs of one symbol (the context repeats while its line is still in flight: the
+    """scl_aec_sparse.hip keeps a context in one 64-byte line (the symbols seen in it) for its first 30 (encoder) / 28 (decoder) symbols and moves
+    it to its dense row with the next: runs of one symbol (the context repeats while its line is still in flight: the
     patch path, also across the move), a few hot contexts that cross the boundary early and many cold ones, symbol
-    K - 1, chunks that end exactly on the 28th / 29th / 30th symbol of a context.  Streams, symbols and consumed bits
+    K - 1, chunks that end exactly on the 28th .. 33rd symbol of a context.  Streams, symbols and consumed bits
     against the oracle."""
     rng = np.random.default_rng(900 + K + k)
     model = models.AecModel(2, None, K, k, 1 << 30, 32, 32)
@@ -157,7 +157,7 @@ def test_batch_aec_large_alphabet_line_to_row_transitions(K, k, dev):
             x = np.full(cap, K - 1 if c % 8 == 3 else 0)
         rows.append(np.resize(x, cap))
     sym = np.stack(rows).astype(np.uint8)
-    lens = np.array([27, 28, 29, 30, 31, 57, 58, 59] + [int(v) for v in rng.integers(0, cap + 1, 15)] + [cap], dtype=np.int32)
+    lens = np.array([28, 29, 30, 31, 32, 33, 61, 62] + [int(v) for v in rng.integers(0, cap + 1, 15)] + [cap], dtype=np.int32)
     sym[:8] = sym[3]  # the single-symbol row: its one context takes exactly lens[i] symbols
     enc = model.encode_batch(torch.from_numpy(sym).to(dev), lens=torch.from_numpy(lens).to(dev))
     dec, dlens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
