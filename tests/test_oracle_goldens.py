@@ -148,3 +148,69 @@ def test_restatement_rans(case):
     for packed, total, used in case.bits_with_garbage:
         sym, got_used = rst.rans_decode_block(p, BitArray.from_packed(packed, total))
         assert got_used == used and sym == case.arr("sym").tolist()
+
+
+def _small(case, limit):
+    if case.n > limit:
+        pytest.skip("per-symbol Python: the long vectors stay with the C oracle")
+
+
+@pytest.mark.parametrize("case", TANS, ids=golden_ids(TANS))
+def test_restatement_tans(case):
+    import scl_restatement as rst
+    from stanford_compression_library_amd.core.prob_dist import Frequencies
+    from stanford_compression_library_amd.utils.bitarray_utils import BitArray
+
+    _small(case, 1100)
+    if case.RF * int(np.sum(case.freq)) > (1 << 16):
+        pytest.skip("the reference-style table builder loops over RANGE_FACTOR * M states in Python")
+    p = rst.TansSetup(Frequencies(dict(enumerate(case.freq))), case.size_bits, case.RF)
+    bits = rst.tans_encode_block(p, case.arr("sym").tolist())
+    assert len(bits) == case.nbits and np.array_equal(bits.packed(), case.arr("out"))
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = rst.tans_decode_block(p, BitArray.from_packed(packed, total))
+        assert got_used == used and sym == case.arr("sym").tolist()
+
+
+@pytest.mark.parametrize("case", RANGE, ids=golden_ids(RANGE))
+def test_restatement_range(case):
+    import scl_restatement as rst
+    from stanford_compression_library_amd.core.prob_dist import Frequencies
+    from stanford_compression_library_amd.utils.bitarray_utils import BitArray
+
+    _small(case, 1100)
+    p = rst.RangeSetup(Frequencies(dict(enumerate(case.freq))), case.precision, case.size_bits)
+    bits = rst.range_encode_block(p, case.arr("sym").tolist())
+    assert len(bits) == case.nbits and np.array_equal(bits.packed(), case.arr("out"))
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = rst.range_decode_block(p, BitArray.from_packed(packed, total))
+        assert got_used == used and sym == case.arr("sym").tolist()
+
+
+@pytest.mark.parametrize("case", AEC, ids=golden_ids(AEC))
+def test_restatement_aec(case):
+    """the arithmetic coder over the package's host model objects (fixed / adaptive i.i.d. incl. the halving rule /
+    order-k k = 0..3), fresh model per block"""
+    import scl_restatement as rst
+    from stanford_compression_library_amd.compressors.probability_models import (AdaptiveIIDFreqModel,
+                                                                                 AdaptiveOrderKFreqModel, FixedFreqModel)
+    from stanford_compression_library_amd.core.prob_dist import Frequencies
+    from stanford_compression_library_amd.utils.bitarray_utils import BitArray
+
+    _small(case, 2100)
+    if case.n == 0:
+        pytest.skip("quirk Q5: the reference's decoder does not terminate on an empty block")
+    p = rst.AecSetup(case.precision, case.size_bits)
+
+    def fresh():
+        if case.model == "fixed":
+            return FixedFreqModel(Frequencies(dict(enumerate(int(f) for f in case.freq))), case.max_total)
+        if case.model == "iid":
+            return AdaptiveIIDFreqModel(Frequencies(dict(enumerate(int(f) for f in case.freq))), case.max_total)
+        return AdaptiveOrderKFreqModel(list(range(case.K)), case.k, case.max_total)
+
+    bits = rst.aec_encode_block(p, fresh(), case.arr("sym").tolist())
+    assert len(bits) == case.nbits and np.array_equal(bits.packed(), case.arr("out"))
+    for packed, total, used in case.bits_with_garbage:
+        sym, got_used = rst.aec_decode_block(p, fresh(), BitArray.from_packed(packed, total))
+        assert got_used == used and sym == case.arr("sym").tolist()
