@@ -78,6 +78,11 @@ extern "C" {
 const char *scl_last_error(void);
 int scl_device_count(int *count);
 int scl_abi_version(void);
+/* Which kernels serve the batch calls of the CALLING THREAD (ABI version 5): on = 1 keeps the tuned kernels out (every call
+   runs the any-parameter kernels -- how the tests compare the two implementations of every coder word for word),
+   on = 0 lets the library choose, on = -1 (the initial state) follows the environment variable
+   SCL_ANY_PARAMETER_KERNELS as before.  Thread-local: other threads' calls are not affected.  Returns the previous value. */
+int scl_set_any_parameter_kernels(int on);
 
 /* ---- rANS ---------------------------------------------------------------------------------- */
 typedef struct scl_rans_model scl_rans_model;
@@ -290,7 +295,32 @@ int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const
  *   Errors: all arguments are checked before anything is posted; after ncclGroupStart the group is closed on every
  *   path (first error recorded, ncclGroupEnd, then return).  A layout that contradicts this rank's own count is
  *   refused on this rank only -- the peers then wait in the exchange, so derive layouts from exchanged counts. */
+/*   scl_rccl_comm_info      : (ABI version 5) what the communicator reports about itself -- ncclCommUserRank /
+ *                             ncclCommCount -- and the device it belongs to;
+ *   scl_rccl_inject_api     : (ABI version 5) TEST HOOK.  Every RCCL operation above goes through one table of eleven
+ *                             plain-C function pointers (scl_rccl_api); by default it is filled from librccl.so on first
+ *                             use, this call replaces it (NULL restores the default).  With host_memory != 0 the
+ *                             buffers handed to the calls above are host memory and the library makes no HIP call on
+ *                             these paths (its own copies are memcpy, the root's offset fix-up a loop): the tests run a
+ *                             W-rank exchange -- layout checks, grouped posts, the root's receive offsets -- inside one
+ *                             process on a machine without a GPU.  Not for production use. */
 typedef struct scl_comm scl_comm;
+typedef struct scl_rccl_api {
+    int (*get_unique_id)(uint8_t *id128);                                       /* ncclGetUniqueId    */
+    int (*comm_init_rank)(void **comm, int nranks, const uint8_t *id128, int rank); /* ncclCommInitRank */
+    int (*comm_destroy)(void *comm);                                            /* ncclCommDestroy    */
+    int (*comm_count)(void *comm, int *nranks);                                 /* ncclCommCount      */
+    int (*comm_user_rank)(void *comm, int *rank);                               /* ncclCommUserRank   */
+    int (*all_gather)(const void *send, void *recv, uint64_t count, int dtype, void *comm, void *stream);
+    int (*send)(const void *buf, uint64_t count, int dtype, int peer, void *comm, void *stream);
+    int (*recv)(void *buf, uint64_t count, int dtype, int peer, void *comm, void *stream);
+    int (*group_start)(void);
+    int (*group_end)(void);
+    const char *(*error_string)(int result);
+    int host_memory; /* 1: buffers are host memory, the library makes no HIP call around the exchange */
+} scl_rccl_api;      /* dtype: 1 = uint8, 5 = uint64 (ncclDataType_t); results: 0 = success */
+int scl_rccl_inject_api(const scl_rccl_api *api);
+int scl_rccl_comm_info(scl_comm *c, int *rank, int *nranks, int *device);
 int scl_rccl_unique_id(uint8_t *id128);
 int scl_rccl_comm_create(const uint8_t *id128, int rank, int world, scl_comm **out);
 void scl_rccl_comm_destroy(scl_comm *c);

@@ -57,6 +57,10 @@ def lib():
         L.orc_aec_decode_st.argtypes = L.orc_aec_decode.argtypes + [u64p]
         L.orc_rans_encode_batch.argtypes = [u8p, u64, u64, u32p, u32, u64, u32, u32, u8p, u64, u64p]
         L.orc_rans_decode_batch.argtypes = [u8p, u64, u64, u64p, u32p, u32, u64, u32, u32, u8p, u64, u64p]
+        L.orc_encode_batch.argtypes = [C.c_int, u8p, u64, u64, u32p, u32, u64, u32, C.c_int, u32, u64, u32, u32, u8p, u64, u64p]
+        L.orc_decode_batch.argtypes = [C.c_int, u8p, u64, u64, u64p, u32p, u32, u64, u32, C.c_int, u32, u64, u32, u32, u8p,
+                                       u64, u64p]
+        L.orc_encode_batch.restype = L.orc_decode_batch.restype = i64
         u16p = C.POINTER(C.c_uint16)
         for base, sym_arg in (("orc_rans_encode", 0), ("orc_rans_decode", 7), ("orc_tans_encode", 0),
                               ("orc_tans_decode", 6), ("orc_range_encode", 0), ("orc_range_decode", 6),
@@ -242,4 +246,40 @@ def rans_decode_batch(streams2d, nbits, freq, chunk_len, RF=1 << 16, b=1, size_b
     _check(lib().orc_rans_decode_batch(_p(streams2d, C.c_uint8), n_chunks, stride, _p(nbits, C.c_uint64),
                                        _p(f, C.c_uint32), f.size, RF, b, size_bits, _p(out, C.c_uint8),
                                        chunk_len, _p(consumed, C.c_uint64)), "rans_decode_batch")
+    return out, consumed
+
+
+CODER_ID = {"rans": 0, "tans": 1, "range": 2, "aec": 3}
+
+
+def encode_batch(coder, sym2d, freq, RF=1 << 16, b=1, model_kind=0, K=None, k=0, max_total=1 << 30, precision=32,
+                 size_bits=32, out_stride=None):
+    """any coder over equally long uint8 chunks, one fresh coder per chunk (ctypes releases the GIL: one call per thread
+    scales over host cores).  ``freq``: the static table, or the initial counts of an adaptive model (ignored for
+    order-k).  -> (streams uint8 [n_chunks, out_stride], nbits uint64 [n_chunks])"""
+    sym2d = _u8(sym2d)
+    n_chunks, chunk_len = sym2d.shape
+    f = _freq(freq if freq is not None else np.ones(K))
+    K = int(K if K is not None else f.size)
+    out_stride = int(out_stride or (chunk_len * 3 + 256))
+    out = np.zeros((n_chunks, out_stride), np.uint8)
+    nbits = np.zeros(n_chunks, np.uint64)
+    _check(lib().orc_encode_batch(CODER_ID[coder], _p(sym2d, C.c_uint8), n_chunks, chunk_len, _p(f, C.c_uint32), K, RF, b,
+                                  model_kind, k, max_total, precision, size_bits, _p(out, C.c_uint8), out_stride,
+                                  _p(nbits, C.c_uint64)), f"{coder}_encode_batch")
+    return out, nbits
+
+
+def decode_batch(coder, streams2d, nbits, freq, chunk_len, RF=1 << 16, b=1, model_kind=0, K=None, k=0, max_total=1 << 30,
+                 precision=32, size_bits=32):
+    streams2d = _u8(streams2d)
+    nbits = np.ascontiguousarray(nbits, np.uint64)
+    n_chunks, stride = streams2d.shape
+    f = _freq(freq if freq is not None else np.ones(K))
+    K = int(K if K is not None else f.size)
+    out = np.zeros((n_chunks, chunk_len), np.uint8)
+    consumed = np.zeros(n_chunks, np.uint64)
+    _check(lib().orc_decode_batch(CODER_ID[coder], _p(streams2d, C.c_uint8), n_chunks, stride, _p(nbits, C.c_uint64),
+                                  _p(f, C.c_uint32), K, RF, b, model_kind, k, max_total, precision, size_bits,
+                                  _p(out, C.c_uint8), chunk_len, _p(consumed, C.c_uint64)), f"{coder}_decode_batch")
     return out, consumed

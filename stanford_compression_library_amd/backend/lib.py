@@ -48,6 +48,7 @@ _SIGNATURES = {
     "scl_last_error": (C.c_char_p, []),
     "scl_device_count": (_int, [C.POINTER(_int)]),
     "scl_abi_version": (_int, []),
+    "scl_set_any_parameter_kernels": (_int, [_int]),
     "scl_rans_model_create": (_int, [_u32p, _u32, _u64, _u32, _u32, C.POINTER(_vp)]),
     "scl_rans_model_destroy": (None, [_vp]),
     "scl_rans_model_info": (_int, [_vp, C.POINTER(RansInfo)]),
@@ -96,6 +97,8 @@ _SIGNATURES = {
     "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),
     "scl_histogram_u8": (_int, [_vp, _u64, _vp, _vp]),
     "scl_histogram_u16": (_int, [_vp, _u64, _u32, _vp, _vp, _vp]),
+    "scl_rccl_inject_api": (_int, [_vp]),
+    "scl_rccl_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "scl_rccl_unique_id": (_int, [_u8p]),
     "scl_rccl_comm_create": (_int, [_u8p, _int, _int, C.POINTER(_vp)]),
     "scl_rccl_comm_destroy": (None, [_vp]),

@@ -27,23 +27,19 @@ def _freq_array(freq_list) -> np.ndarray:
 
 
 class _any_parameter:
-    """context manager: the library's tuned kernels are kept out while it is active (csrc/scl_core.hip reads
-    ``SCL_ANY_PARAMETER_KERNELS`` at every batch call)"""
+    """context manager: the library's tuned kernels are kept out of THIS THREAD's batch calls while it is active
+    (``scl_set_any_parameter_kernels``, a thread-local switch of the C ABI -- the process environment is not touched)"""
 
     def __init__(self, on: bool):
         self.on = bool(on)
 
     def __enter__(self):
         if self.on:
-            self.prev = os.environ.get("SCL_ANY_PARAMETER_KERNELS")
-            os.environ["SCL_ANY_PARAMETER_KERNELS"] = "1"
+            self.prev = _lib.load().scl_set_any_parameter_kernels(1)
 
     def __exit__(self, *exc):
         if self.on:
-            if self.prev is None:
-                os.environ.pop("SCL_ANY_PARAMETER_KERNELS", None)
-            else:
-                os.environ["SCL_ANY_PARAMETER_KERNELS"] = self.prev
+            _lib.load().scl_set_any_parameter_kernels(self.prev)
         return False
 
 
@@ -151,6 +147,11 @@ class _DeviceModel:
         if not hasattr(self, "_scratch_by_stream"):
             self._scratch_by_stream = {}
         if isinstance(stream_handle, tuple):  # encode_rows_into: one scratch per sub-batch, kept until replaced
+            # ("rows", first row, rows of the whole shard): a shard of another shape starts over, so that a changing
+            # shard shape cannot pile up one scratch per sub-batch start ever seen
+            shard = stream_handle[2]
+            for k in [k for k in self._scratch_by_stream if isinstance(k, tuple) and k[2] != shard]:
+                del self._scratch_by_stream[k]
             self._scratch_by_stream[stream_handle] = scratch
             return
         self._scratch_by_stream[int(stream_handle or 0)] = scratch
@@ -216,7 +217,7 @@ class _DeviceModel:
         if self._needs_scratch:
             scratch, nbytes = self._scratch(b - a, sym.device)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
-            self._keep_scratch(("rows", a), scratch)
+            self._keep_scratch(("rows", a, n_rows), scratch)
         with torch.cuda.device(sym.device):
             rc = self._fn("encode_batch")(*args, stream_handle)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")

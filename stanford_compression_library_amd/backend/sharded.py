@@ -85,6 +85,16 @@ class RcclGather:
         except Exception:
             pass
 
+    def info(self) -> dict:
+        """what the communicator reports about itself (``ncclCommUserRank`` / ``ncclCommCount``) and its device"""
+        r, n, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        self._check(self._L.scl_rccl_comm_info(self._h, C.byref(r), C.byref(n), C.byref(d)), "scl_rccl_comm_info")
+        return dict(rank=r.value, nranks=n.value, device=d.value)
+
+    @property
+    def nranks(self) -> int:
+        return self.info()["nranks"]
+
     def counts(self, value: int, stream=None) -> np.ndarray:
         """one u64 of every rank, in rank order (collective; synchronises the stream)"""
         import torch
@@ -183,7 +193,9 @@ def gather_streams_to_root(dense, offsets, world: int, rank: int, device=None, d
     my_bytes = int(offsets[-1].item())
     if comm is not None:
         # one collective for both numbers: payload bytes in the low 40 bits, chunk count above
-        assert my_bytes < (1 << 40) and n_local < (1 << 24)
+        if my_bytes >= (1 << 40) or n_local >= (1 << 24):
+            raise ValueError(f"gather_streams_to_root: {my_bytes} bytes / {n_local} chunks per rank exceed the packed count "
+                             "(40 bits of bytes, 24 bits of chunks)")
         packed = comm.counts(my_bytes | (n_local << 40))
         sizes, counts = (packed & np.uint64((1 << 40) - 1)).astype(np.int64), (packed >> np.uint64(40)).astype(np.int64)
         base = np.concatenate([[0], np.cumsum(sizes)])
@@ -397,7 +409,15 @@ def encode_gather_overlapped(model, sym, world: int, rank: int, n_sub: Optional[
     comm_stream.synchronize()
     comp.synchronize()
     total_ms = (time.perf_counter() - t0) * 1e3
-    torch.cuda.current_stream(dev).wait_stream(comm_stream)
+    cur = torch.cuda.current_stream(dev)
+    cur.wait_stream(comm_stream)
+    # the root's receive tensors were allocated on the communication stream and are handed to a caller who works on the
+    # current one: tell the caching allocator, or a block freed by the caller could be handed out again on the
+    # communication stream while the caller's kernels still read it
+    for r in results:
+        for t in r[1:]:
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
     timings = {"overlapped_ms": round(total_ms, 3), "sub_batches": n_sub,
                "gathered_bytes": int(sum(r[0] for r in results))}
     return timings, ([(r[1], r[2]) for r in results] if rank == dst else None)

@@ -53,7 +53,15 @@ int scl_check_device(int model_device, const char *what) {
 }
 
 // ---- rows the tuned kernels cannot take as they are ----------------------------------------------------
+// per thread: -1 = follow the environment (read at every call), 0 = the library chooses, 1 = any-parameter kernels only
+static thread_local int tl_any_parameter = -1;
+extern "C" int scl_set_any_parameter_kernels(int on) {
+    const int prev = tl_any_parameter;
+    tl_any_parameter = on < 0 ? -1 : (on ? 1 : 0);
+    return prev;
+}
 bool scl_force_generic(void) {
+    if (tl_any_parameter >= 0) return tl_any_parameter == 1;
     const char *e = getenv("SCL_ANY_PARAMETER_KERNELS");
     return e && e[0] == '1';
 }
