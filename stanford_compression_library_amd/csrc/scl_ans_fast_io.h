@@ -617,10 +617,19 @@ struct AnsBitReader {
     u32 bias;        // consumed bits = 32*nrd() - sh - bias
 
     __device__ __forceinline__ void load_line(u64 j) {  // whole 128-byte line: one HBM burst instead of two
+        // Every line but the buffer's last is readable as a whole: ONE comparison and eight loads off one address.  (Eight
+        // separately bounds-checked loads -- compare, zero default, branch, each -- were 70 instructions per line, a fifth
+        // of the rANS decoder's vector instructions.)
+        if (j * 8 + 8 <= n_blocks16) {
+            const uint4 *p = base + j * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const u64 idx = j * 8 + i;
-            pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 8; ++i) pf[i] = p[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u64 idx = j * 8 + i;
+                pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+            }
         }
     }
     __device__ __forceinline__ void push_half(char *lds, const uint4 &q0, const uint4 &q1, const uint4 &q2,
@@ -719,6 +728,7 @@ struct AnsBitReader {
     }
     __device__ __forceinline__ u32 consumed() const { return 32 * nrd() - sh - bias; }
     __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, sh); }
+    __device__ __forceinline__ u32 look(const char *) const { return look(); }
     __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
         if (__builtin_usub_overflow(sh, nb, &sh)) {
             A = B;
@@ -728,6 +738,150 @@ struct AnsBitReader {
     }
     __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32
         const u32 v = look() >> (32 - w);
+        advance(lds, w);
+        return v;
+    }
+};
+
+
+// Round-4 reader: no bit window in registers.  AnsBitReader keeps two ring words (A, B) in registers and advances
+// them under a branch that the whole wave runs for every pair of symbols (some lane always crosses a word: 5 VALU + 2 SALU
+// + the branch per pair).  Here the lookahead of a pair is read straight out of the ring by BIT POSITION: the two words
+// around the position (two conflict-free ds_read_b32 of the lane's column) and one v_alignbit -- no branch, no window to
+// shift, two VALU instructions less per pair (the rANS decoder issues 12.8 VALU per symbol at 77-80 % of one per four
+// clocks: instruction COUNT is what bounds it).
+//   N = -(bits consumed since bit 0 of the lane's first 128-byte line): v_alignbit reads its low five bits, which is the
+//       shift that brings the position's bit to the top -- for a position on a word boundary that shift is 0 and the
+//       result is the SECOND word, so the first word read is the one holding the bit BEFORE the position:
+//   P = (position - 1) << RSH: P & ROWMASK is that word's ring row (byte address without the thread column).
+// Same ring, same line-granular refill and the same call cadence as AnsBitReader.
+template <int THREADS, bool ZERO_PAST_END = false>
+struct AnsBitReaderW {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
+    static constexpr u32 ROW = THREADS * 4u;
+    static constexpr u32 RSH = THREADS == 1024 ? 7u : (THREADS == 512 ? 6u : (THREADS == 256 ? 5u : 4u));  // log2(ROW) - 5
+    static constexpr u32 ROWMASK = 31u * ROW;
+    static_assert((32u << RSH) == ROW, "THREADS must be 128, 256, 512 or 1024");
+    u32 wabs;      // ZERO_PAST_END: index (from the buffer start) of the next word that enters the ring
+    u32 end_word;  //                index of the word holding the first bit after the stream
+    u32 end_mask;  //                bits of that word which still belong to the stream
+    const uint4 *base;
+    u64 n_blocks16;  // readable 16-byte blocks
+    u64 next_line;   // index of the next 128-byte line to prefetch
+    uint4 pf[8];     // prefetched line: its two 64-byte halves enter the ring one at a time
+    u32 stage;       // 0: the lower half of pf is next, 1: the upper half
+    u32 wa;          // LDS byte address of the ring half that is filled next
+    u32 N, P;        // see above
+    u32 col;         // tid * 4
+    u32 rowA;        // LDS byte address of the first word the last look() read: rows from here on are still needed
+    u32 start;       // bit position at init
+
+    __device__ __forceinline__ void load_line(u64 j) {  // whole 128-byte line: one HBM burst instead of two
+        // Every line but the buffer's last is readable as a whole: ONE comparison and eight loads off one address.  (Eight
+        // separately bounds-checked loads -- compare, zero default, branch, each -- were 70 instructions per line, a fifth
+        // of the rANS decoder's vector instructions.)
+        if (j * 8 + 8 <= n_blocks16) {
+            const uint4 *p = base + j * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[i] = p[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u64 idx = j * 8 + i;
+                pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void push_half(char *lds, const uint4 &q0, const uint4 &q1, const uint4 &q2,
+                                              const uint4 &q3) {
+        char *r = lds + wa;
+        const uint4 blk[4] = {q0, q1, q2, q3};
+        if (ZERO_PAST_END && wabs + 16 > end_word) {  // the half that holds the end of the stream, or lies past it
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 w4[4] = {blk[i].x, blk[i].y, blk[i].z, blk[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 wi = wabs + 4 * i + j;
+                    const u32 keep = (wi < end_word) ? 0xFFFFFFFFu : (wi == end_word ? end_mask : 0u);
+                    *reinterpret_cast<u32 *>(r + (4 * i + j) * ROW) = __builtin_bswap32(w4[j]) & keep;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<u32 *>(r + (4 * i + 0) * ROW) = __builtin_bswap32(blk[i].x);
+                *reinterpret_cast<u32 *>(r + (4 * i + 1) * ROW) = __builtin_bswap32(blk[i].y);
+                *reinterpret_cast<u32 *>(r + (4 * i + 2) * ROW) = __builtin_bswap32(blk[i].z);
+                *reinterpret_cast<u32 *>(r + (4 * i + 3) * ROW) = __builtin_bswap32(blk[i].w);
+            }
+        }
+        if (ZERO_PAST_END) wabs += 16;
+        wa ^= 16 * ROW;
+    }
+    // rows from the first one still needed up to the newest, minus one, in ring-address units.  The writer may fill the
+    // half at `wa` once at most 16 rows are left ahead of rowA: that half then lies wholly behind the reader.  A check
+    // that finds 17 rows and does nothing still leaves 4 after the <= 13 words of the next 32 symbols -- the position's
+    // two words and one to spare.
+    __device__ __forceinline__ u32 ahead_m1() const { return (wa - rowA - ROW) & (RING_BYTES - 1); }
+    // call at least every 32 symbols of <= 13 bits
+    __device__ __forceinline__ void maybe_refill(char *lds) {
+        if (ahead_m1() < 16 * ROW) {
+            if (stage == 0) {
+                push_half(lds, pf[0], pf[1], pf[2], pf[3]);
+                stage = 1;
+            } else {
+                push_half(lds, pf[4], pf[5], pf[6], pf[7]);
+                stage = 0;
+                load_line(next_line++);
+            }
+        }
+    }
+    __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, char *lds, u32 tid,
+                                         u32 nbits = 0) {
+        base = reinterpret_cast<const uint4 *>(in);
+        n_blocks16 = in_size_bytes >> 4;
+        const u64 j0 = bit_off >> 10;
+        if (ZERO_PAST_END) {  // (streams and buffers are below 2^37 bits: word indices fit 32 bits)
+            const u64 end = bit_off + nbits;
+            wabs = (u32)(j0 * 32);
+            end_word = (u32)(end >> 5);
+            end_mask = ~(0xFFFFFFFFu >> (end & 31u)) & (0u - (u32)((end & 31u) != 0));
+        }
+        col = tid * 4;
+        wa = col;
+        load_line(j0);
+        push_half(lds, pf[0], pf[1], pf[2], pf[3]);
+        push_half(lds, pf[4], pf[5], pf[6], pf[7]);
+        load_line(j0 + 1);
+        next_line = j0 + 2;
+        stage = 0;
+        start = (u32)bit_off & 1023u;
+        N = 0u - start;
+        P = (start - 1u) << RSH;
+        rowA = ((start >> 5) * ROW) | col;  // the word of the position itself (the one before it is never needed again)
+        // a stream that starts in the upper half of its line has fewer than 17 words ahead of it: top the ring up before
+        // the first word is read (the lower half of the ring is already behind the read position)
+        maybe_refill(lds);
+    }
+    __device__ __forceinline__ u32 consumed() const { return (0u - N) - start; }
+    // the 32 bits at the position (the ring always holds the two words around it)
+    __device__ __forceinline__ u32 look(const char *lds) {
+        const u32 a = (P & ROWMASK) | col;            // v_and_or
+        const u32 b = ((P + ROW) & ROWMASK) | col;    // v_add + v_and_or
+        rowA = a;
+        const u32 A = *reinterpret_cast<const u32 *>(lds + a);
+        const u32 B = *reinterpret_cast<const u32 *>(lds + b);
+        return __builtin_amdgcn_alignbit(A, B, N);
+    }
+    __device__ __forceinline__ void advance(const char *, u32 nb) {  // any nb
+        N -= nb;
+        // one v_lshl_add; written out because the compiler re-associates P into (initial P) + (running sum << RSH), an add
+        // more per pair
+        asm("v_lshl_add_u32 %0, %1, %2, %0" : "+v"(P) : "v"(nb), "n"(RSH));
+    }
+    __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32
+        const u32 v = look(lds) >> (32 - w);
         advance(lds, w);
         return v;
     }

@@ -34,6 +34,15 @@
 #include "scl_rans_internal.h"
 
 #define RF_THREADS 256
+#ifndef RD_WINDOWLESS
+#define RD_WINDOWLESS 1  // 0: the round-1..3 reader (two ring words in registers, advanced under a branch per pair)
+#endif
+#ifndef RF_WAITMERGE
+#define RF_WAITMERGE 0
+#endif
+#ifndef RD_PERM_PAIRS
+#define RD_PERM_PAIRS 1  // 0: one v_perm per decoded symbol
+#endif
 #ifndef RF_COOP_STORE
 #define RF_COOP_STORE 1  // 0 (timing experiment): every lane stores its own lines
 #endif
@@ -141,6 +150,11 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
         const Entries4 cur = pre;
         pre.load(wv[d + 1], tab);
         asm volatile("" ::: "memory");  // keep the reads here: the compiler would sink them to their first use
+#if RF_WAITMERGE
+        // the four entries of this word were issued back to back a whole word ago: touching the LAST of them first makes the
+        // compiler wait once (lgkmcnt(4): only the reads just issued may still be in flight) instead of once per symbol
+        asm volatile("" : : "v"(cur.e[3].k_lo));
+#endif
         if (CHECK_SYM) {
             const u32 w = wv[d];
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
@@ -365,23 +379,37 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
     u32 ow[4];
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
-        u32 o = 0;
+        u32 pr[2] = {0u, 0u};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            u32 lk = r.look();
+            u32 lk = r.look(lds);
             u32 ua, ub;
             const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt, rf_gen);
             const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk, ub, tab, ml_rt, cb_rt, rf_gen);
             // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead (the top-aligned variant reports clz, 3 more
             // per symbol than it read)
             r.advance(lds, (ML_T > 0 && CB_T == 3) ? ua + ub - 6u : ua + ub);
-            o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
-            o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
+#if RD_PERM_PAIRS
+            // the symbol bytes of a pair with ONE v_perm (the earlier symbol is the more significant byte), the two pairs
+            // of a word with another: three instead of four per four symbols
+            u32 p = __builtin_amdgcn_perm(ea, eb, 0x0c0c0703u);  // 0 : 0 : ea >> 24 : eb >> 24
             // the chain through x is serial anyway; without this fence the compiler sinks all the byte inserts
             // of a 64-symbol iteration to its end, keeps every table word alive until then and spills
+            asm volatile("" : "+v"(p) : : "memory");
+            pr[h] = p;
+#else
+            u32 o = pr[0];
+            o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
+            o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
             asm volatile("" : "+v"(o) : : "memory");
+            pr[0] = pr[1] = o;
+#endif
         }
-        ow[d] = o;
+#if RD_PERM_PAIRS
+        ow[d] = __builtin_amdgcn_perm(pr[0], pr[1], 0x05040100u);
+#else
+        ow[d] = pr[1];
+#endif
     }
     if (REFILL) r.maybe_refill(lds);
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
@@ -398,7 +426,11 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
                                                                      u32 *__restrict__ status) {
     // slot table first: its offsets (< 32 KiB) then need no base added (a DS offset field reaches 64 KiB); the ring
     // works on addresses relative to its own base, which the DS offset field supplies
+#if RD_WINDOWLESS
+    typedef AnsBitReaderW<THREADS> DecIn;
+#else
     typedef AnsBitReader<THREADS> DecIn;
+#endif
     __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + DecIn::RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
@@ -440,7 +472,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
-        u32 used, lk1 = r.look();
+        u32 used, lk1 = r.look(lds);
         const u32 e = rf_decode_symbol<ML_T, CB_T>(x, lk1, used, tab, ml_rt, cb_rt, rf_gen);
         r.advance(lds, used - XSH);
         dst[--i] = (u8)(e >> 24);

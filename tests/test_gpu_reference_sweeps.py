@@ -1,0 +1,219 @@
+"""The reference's own hot-path tests, run against this package through its mirrored harness.
+
+Each test below is one of the reference's inline tests with the import prefix changed from ``scl`` to
+``stanford_compression_library_amd`` -- the same frequency tables, parameter sets, data sizes, seeds and tolerances, the
+same harness calls (``try_lossless_compression`` / ``lossless_entropy_coder_test`` /
+``lossless_test_against_expected_bitrate`` with trailing garbage):
+
+  test_rANS_coding                          scl/compressors/rANS.py:363-401
+  test_tANS_coding                          scl/compressors/tANS.py:418-452
+  test_arithmetic_coding                    scl/compressors/arithmetic_coding.py:297-333
+  test_adaptive_arithmetic_coding           scl/compressors/arithmetic_coding.py:336-381
+  test_adaptive_order_k_arithmetic_coding   scl/compressors/arithmetic_coding.py:384-463 (incl. the 2nd-order Markov source)
+  test_range_coding                         scl/compressors/range_coder.py:320-374
+
+Bit-exactness of the same parameter sets is pinned by the golden fixtures (tests/test_gpu_goldens.py); this file shows
+the drop-in claim the way the reference tests itself.  Trailing garbage comes from numpy's global generator like the
+reference's; it is seeded per test so that a failure reproduces.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from stanford_compression_library_amd.compressors.arithmetic_coding import AECParams, ArithmeticDecoder, ArithmeticEncoder
+from stanford_compression_library_amd.compressors.probability_models import AdaptiveIIDFreqModel, AdaptiveOrderKFreqModel
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.prob_dist import Frequencies, get_avg_neg_log_prob
+from stanford_compression_library_amd.utils.test_utils import (get_random_data_block, lossless_entropy_coder_test,
+                                                               lossless_test_against_expected_bitrate,
+                                                               try_lossless_compression)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _seed_trailing_bits():
+    np.random.seed(20240928)
+
+
+def test_rANS_coding():
+    freqs_list = [
+        Frequencies({"A": 1, "B": 1, "C": 2}),
+        Frequencies({"A": 12, "B": 34, "C": 1, "D": 45}),
+        Frequencies({"A": 34, "B": 35, "C": 546, "D": 1, "E": 13, "F": 245}),
+        Frequencies({"A": 5, "B": 5, "C": 5, "D": 5, "E": 5, "F": 5}),
+        Frequencies({"A": 1, "B": 3}),
+    ]
+    params_list = [
+        rANSParams(freqs_list[0]),
+        rANSParams(freqs_list[1]),
+        rANSParams(freqs_list[2], NUM_BITS_OUT=8),
+        rANSParams(freqs_list[3], RANGE_FACTOR=1 << 12),
+        rANSParams(freqs_list[4], RANGE_FACTOR=1 << 4),
+    ]
+    DATA_SIZE = 10000
+    SEED = 0
+    for freq, rans_params in zip(freqs_list, params_list):
+        prob_dist = freq.get_prob_dist()
+        data_block = get_random_data_block(prob_dist, DATA_SIZE, seed=SEED)
+        avg_log_prob = get_avg_neg_log_prob(prob_dist, data_block)
+        encoder = rANSEncoder(rans_params)
+        decoder = rANSDecoder(rans_params)
+        is_lossless, encode_len, _ = try_lossless_compression(
+            data_block, encoder, decoder, add_extra_bits_to_encoder_output=True
+        )
+        assert is_lossless
+        avg_codelen = encode_len / data_block.size
+        print(f"rANS coding: avg_log_prob={avg_log_prob:.3f}, rANS codelen: {avg_codelen:.3f}")
+        assert avg_codelen < avg_log_prob + 0.1  # (not asserted by the reference; a coder this far off would be broken)
+
+
+def test_tANS_coding():
+    freqs_list = [
+        Frequencies({"A": 1, "B": 1, "C": 2}),
+        Frequencies({"A": 1, "B": 3}),
+        Frequencies({"A": 3, "B": 4, "C": 9}),
+    ]
+    params_list = [
+        tANSParams(freqs_list[0], RANGE_FACTOR=1),
+        tANSParams(freqs_list[1], RANGE_FACTOR=1 << 4),
+        tANSParams(freqs_list[2]),
+    ]
+    DATA_SIZE = 10000
+    SEED = 0
+    for freq, tans_params in zip(freqs_list, params_list):
+        prob_dist = freq.get_prob_dist()
+        data_block = get_random_data_block(prob_dist, DATA_SIZE, seed=SEED)
+        avg_log_prob = get_avg_neg_log_prob(prob_dist, data_block)
+        encoder = tANSEncoder(tans_params)
+        decoder = tANSDecoder(tans_params)
+        is_lossless, encode_len, _ = try_lossless_compression(
+            data_block, encoder, decoder, add_extra_bits_to_encoder_output=True
+        )
+        assert is_lossless
+        avg_codelen = encode_len / data_block.size
+        print(f"tANS coding: avg_log_prob={avg_log_prob:.3f}, tANS codelen: {avg_codelen:.3f}")
+
+
+AEC_FREQS = [
+    Frequencies({"A": 1, "B": 1, "C": 2}),
+    Frequencies({"A": 12, "B": 34, "C": 1, "D": 45}),
+    Frequencies({"A": 34, "B": 35, "C": 546, "D": 1, "E": 13, "F": 245}),
+    Frequencies({"A": 5, "B": 5, "C": 5, "D": 5, "E": 5, "F": 5}),
+]
+AEC_PARAMS = [
+    dict(),
+    dict(),
+    dict(DATA_BLOCK_SIZE_BITS=12),
+    dict(DATA_BLOCK_SIZE_BITS=12, PRECISION=16),
+]
+
+
+def test_arithmetic_coding():
+    """the model starts from the data's own frequencies (arithmetic_coding.py:297-333)"""
+    DATA_SIZE = 1000
+    for freq, kw in zip(AEC_FREQS, AEC_PARAMS):
+        params = AECParams(**kw)
+        freq_model_enc = AdaptiveIIDFreqModel(freq, max_allowed_total_freq=params.MAX_ALLOWED_TOTAL_FREQ)
+        freq_model_dec = copy.deepcopy(freq_model_enc)
+        encoder = ArithmeticEncoder(params, freq_model_enc)
+        decoder = ArithmeticDecoder(params, freq_model_dec)
+        lossless_entropy_coder_test(encoder, decoder, freq, DATA_SIZE, encoding_optimality_precision=1e-1, seed=0)
+
+
+def test_adaptive_arithmetic_coding():
+    """the model starts uniform and learns (arithmetic_coding.py:336-381)"""
+    DATA_SIZE = 1000
+    for freq, kw in zip(AEC_FREQS, AEC_PARAMS):
+        params = AECParams(**kw)
+        uniform_dist = Frequencies({a: 1 for a in freq.alphabet})
+        freq_model_enc = AdaptiveIIDFreqModel(
+            freqs_initial=uniform_dist, max_allowed_total_freq=params.MAX_ALLOWED_TOTAL_FREQ
+        )
+        freq_model_dec = copy.deepcopy(freq_model_enc)
+        encoder = ArithmeticEncoder(params, freq_model_enc)
+        decoder = ArithmeticDecoder(params, freq_model_dec)
+        lossless_entropy_coder_test(encoder, decoder, freq, DATA_SIZE, encoding_optimality_precision=1e-1, seed=0)
+
+
+def _generate_2nd_order_markov(num_samples: int, seed: int = 0):
+    """X_n = X_{n-1} + X_{n-2} + Ber(1/2) mod 3 on {0, 1, 2}: entropy rate 1 bit/symbol, uniform stationary distribution
+    (the reference's test source, arithmetic_coding.py:384-402; same generator calls, hence the same samples)"""
+    assert num_samples >= 3
+    rng = np.random.default_rng(seed)
+    random_bits = rng.choice(2, size=num_samples - 2)
+    x = np.zeros(num_samples, dtype=np.uint8)
+    x[0] = rng.choice(3)
+    x[1] = rng.choice(3)
+    for i in range(2, num_samples):
+        x[i] = (x[i - 1] + x[i - 2] + random_bits[i - 2]) % 3
+    return DataBlock(x)
+
+
+def test_adaptive_order_k_arithmetic_coding():
+    DATA_SIZE = 10000
+    data_block = _generate_2nd_order_markov(DATA_SIZE)
+    for model_params, expected_bitrate in [
+        (([0, 1, 2], 0), np.log2(3)),
+        (([0, 1, 2], 1), np.log2(3)),
+        (([0, 1, 2], 2), 1),
+        (([0, 1, 2], 3), 1),
+    ]:
+        aec_params = AECParams()
+        freq_model_enc = AdaptiveOrderKFreqModel(
+            alphabet=model_params[0], k=model_params[1], max_allowed_total_freq=aec_params.MAX_ALLOWED_TOTAL_FREQ,
+        )
+        freq_model_dec = copy.deepcopy(freq_model_enc)
+        encoder = ArithmeticEncoder(aec_params, freq_model_enc)
+        decoder = ArithmeticDecoder(aec_params, freq_model_dec)
+        lossless_test_against_expected_bitrate(encoder, decoder, data_block, expected_bitrate, 0.1)
+
+    # order 0 is the adaptive i.i.d. model, bit for bit
+    params = AECParams()
+    freq_model_orderk = AdaptiveOrderKFreqModel(
+        alphabet=[0, 1, 2], k=0, max_allowed_total_freq=params.MAX_ALLOWED_TOTAL_FREQ
+    )
+    encoder1 = ArithmeticEncoder(params, freq_model_orderk)
+    uniform_dist = Frequencies({0: 1, 1: 1, 2: 1})
+    freq_model_iid = AdaptiveIIDFreqModel(uniform_dist, max_allowed_total_freq=params.MAX_ALLOWED_TOTAL_FREQ)
+    encoder2 = ArithmeticEncoder(params, freq_model_iid)
+    assert encoder1.encode_block(data_block) == encoder2.encode_block(data_block)
+
+
+def _test_range_coding(freq, input):
+    data_block = DataBlock(input)
+    encoder = RangeEncoder(RangeCoderParams(), freq)
+    decoder = RangeDecoder(RangeCoderParams(), freq)
+    is_lossless, _, _ = try_lossless_compression(data_block, encoder, decoder, add_extra_bits_to_encoder_output=True)
+    assert is_lossless
+
+
+def test_range_coding():
+    DATA_SIZE = 10000
+    freqs = [
+        Frequencies({"A": 1, "B": 1, "C": 2}),
+        Frequencies({"A": 12, "B": 34, "C": 1, "D": 45}),
+        Frequencies({"A": 34, "B": 35, "C": 546, "D": 1, "E": 13, "F": 245}),
+        Frequencies({"A": 1, "C": 65534}),
+    ]
+    for freq in freqs:
+        encoder = RangeEncoder(RangeCoderParams(), freq)
+        decoder = RangeDecoder(RangeCoderParams(), freq)
+        lossless_entropy_coder_test(encoder, decoder, freq, DATA_SIZE, encoding_optimality_precision=0.1)
+
+    # edge cases and specific inputs: extreme frequencies, alternations, constant runs
+    _test_range_coding(Frequencies({"A": 1, "C": 65535}), ["A", "C"] * 5000)
+    _test_range_coding(Frequencies({"A": 1, "B": 1, "C": 65534}), ["A", "B", "C"] * 2000)
+    _test_range_coding(Frequencies({"A": 1, "B": 1, "C": 65534}), ["A"] * 5000)
+    _test_range_coding(Frequencies({"A": 1, "B": 1, "C": 65534}), ["C"] * 5000)
+
+    # every length 0..49 (flush behaviour)
+    freq = Frequencies({"A": 12, "B": 34, "C": 1, "D": 45})
+    prob_dist = freq.get_prob_dist()
+    data_block = get_random_data_block(prob_dist, 5000, seed=0)
+    for l in range(0, 50):
+        _test_range_coding(freq, data_block.data_list[:l])
