@@ -37,8 +37,11 @@
 #ifndef RD_WINDOWLESS
 #define RD_WINDOWLESS 1  // 0: the round-1..3 reader (two ring words in registers, advanced under a branch per pair)
 #endif
+#ifndef RF_UNROLL2
+#define RF_UNROLL2 0  // 1: the encoder's line loop handles two lines per iteration (no copy of the prefetched line)
+#endif
 #ifndef RF_WAITMERGE
-#define RF_WAITMERGE 0
+#define RF_WAITMERGE 1  // 0: one s_waitcnt per symbol for its table entry (round 3)
 #endif
 #ifndef RD_PERM_PAIRS
 #define RD_PERM_PAIRS 1  // 0: one v_perm per decoded symbol
@@ -238,36 +241,61 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
         }
         pre.load(cur.v[0].x, tab);
     }
-#pragma nounroll
-    for (u32 t = 0; t < n_lines; ++t) {
-        // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a
-        // load under a lane-dependent condition is merged with the old value, i.e. waited for, at once
+    // one line = eight blocks of 16 symbols, straight-line code: an inner loop holding only stores would make the compiler
+    // drain vmcnt in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once.
+    // Flush points every 64 symbols (<= 26 new words on top of <= 31 pending, ring of 64) -- after the symbols 32 and 96 of
+    // the line, NOT 64 and 128: the wait for the prefetched line at the end of the iteration is an s_waitcnt vmcnt(0)
+    // (loads and stores share one in-order counter and the stores sit in conditional code, so the compiler cannot count
+    // them), i.e. it also waits for every store issued so far to COMPLETE; stores issued just before it cost their whole
+    // round trip.  (The first word of the next line is only known once the prefetch has landed: its entries are read after
+    // the line.)
+#define RF_ENCODE_LINE(L)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+        rf_encode16<CHECK_SYM, MSH_T, R_T>(L.v[i], i < 7 ? L.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt); \
+        if ((i & EncOut::FLUSH_MASK) == EncOut::FLUSH_PHASE) RF_FLUSH();                                               \
+    }
+    // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a load
+    // under a lane-dependent condition is merged with the old value, i.e. waited for, at once
 #if RF_ABLATE & 8  // timing experiment 8: no input loads after the first line
-        nxt = cur;
-        asm volatile("" : "+v"(nxt.v[0].x));
+#define RF_LOAD_LINE(L, T)                    \
+    do {                                      \
+        L = cur;                              \
+        asm volatile("" : "+v"(L.v[0].x));    \
+    } while (0)
 #else
-        if (coop_in)
-            nxt.load_coop(cp16 + 8 * min(t + 1, n_lines - 1), step16);
-        else
-            nxt.load(src16 + 8 * min(t + 1, n_lines - 1));
+#define RF_LOAD_LINE(L, T)                                                  \
+    do {                                                                    \
+        if (coop_in)                                                        \
+            L.load_coop(cp16 + 8 * min((T), n_lines - 1), step16);          \
+        else                                                                \
+            L.load(src16 + 8 * min((T), n_lines - 1));                      \
+    } while (0)
 #endif
-        // straight-line code for the whole line: an inner loop holding only stores would make the compiler drain vmcnt
-        // in its preheader (SIInsertWaitcnts::shouldFlushVmCnt), i.e. wait for the prefetch at once
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // (the first word of the next line is only known once the prefetch has landed: its entries are read below)
-            rf_encode16<CHECK_SYM, MSH_T, R_T>(cur.v[i], i < 7 ? cur.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
-            // every 64 symbols (<= 26 new words on top of <= 31 pending, ring of 64) -- after the symbols 32 and 96 of the
-            // line, NOT 64 and 128: the wait for the prefetched line at the end of the iteration is an s_waitcnt vmcnt(0)
-            // (loads and stores share one in-order counter and the stores sit in conditional code, so the compiler cannot
-            // count them), i.e. it also waits for every store issued so far to COMPLETE; stores issued just before it
-            // cost their whole round trip
-            if ((i & EncOut::FLUSH_MASK) == EncOut::FLUSH_PHASE) RF_FLUSH();
-        }
+    u32 t = 0;
+#if RF_UNROLL2
+    // two lines per iteration, the two register buffers taking turns: no 32-register copy per line
+#pragma nounroll
+    for (; t + 2 <= n_lines; t += 2) {
+        RF_LOAD_LINE(nxt, t + 1);
+        RF_ENCODE_LINE(cur)
+        if (coop_in) scl_transpose8(nxt.v);
+        pre.load(nxt.v[0].x, tab);
+        RF_LOAD_LINE(cur, t + 2);
+        RF_ENCODE_LINE(nxt)
+        if (coop_in) scl_transpose8(cur.v);
+        pre.load(cur.v[0].x, tab);
+    }
+#endif
+#pragma nounroll
+    for (; t < n_lines; ++t) {
+        RF_LOAD_LINE(nxt, t + 1);
+        RF_ENCODE_LINE(cur)
         cur = nxt;
         if (coop_in) scl_transpose8(cur.v);
         pre.load(cur.v[0].x, tab);
     }
+#undef RF_ENCODE_LINE
+#undef RF_LOAD_LINE
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
         const uint4 v = *reinterpret_cast<const uint4 *>(src + i);

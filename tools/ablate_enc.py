@@ -21,7 +21,7 @@ for _ in range(int(os.environ.get('WARM', 20))):
 torch.cuda.synchronize()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 te = td = 0
-REPS = int(os.environ.get('REPS', 30))
+REPS = int(os.environ.get("TREPS", os.environ.get("REPS", 30)))
 for _ in range(REPS):
     e[0].record(); model.encode_batch(sym, out=enc); e[1].record()
     model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec); e[2].record()
