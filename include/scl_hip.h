@@ -108,6 +108,11 @@ int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_fac
                           uint32_t num_bits_out, uint32_t size_bits, scl_rans_model **out);
 void scl_rans_model_destroy(scl_rans_model *m);
 int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info);
+/* (ABI version 5) which encoder a batch of n_chunks aligned, equally long rows would run with the calling thread's
+   current settings: 'L' / 'S' = tuned NUM_BITS_OUT = 1 kernels with the 256-byte-ring / slot-ring writer (chosen by batch
+   size; SCL_RANS_ENC_WRITER=L|S in the environment forces one, read at every call), 'B' = tuned NUM_BITS_OUT > 1
+   kernels, 'G' = any-parameter kernels.  For tests and tools. */
+int scl_rans_encoder_kind(const scl_rans_model *m, uint64_t n_chunks);
 /* bytes a slot must have so that any block of n symbols fits (multiple of 128: whole cache lines, so the
    64-byte store bursts of the fast kernels never straddle a sector) */
 uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols);

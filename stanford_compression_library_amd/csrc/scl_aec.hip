@@ -723,21 +723,21 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
         aec_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     if (tuned && aec_iid_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
         out_stride >= scl_round_up(out_cap, 4)) {
         aec_iid_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                               out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     if (tuned && aec_static_ok(m) && ((uintptr_t)d_in & 15) == 0 && in_size_bytes < (1ull << 34) &&
         ((uintptr_t)d_out_sym & 15) == 0 && (out_stride & 15) == 0 && out_stride >= out_cap) {
         aec_static_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                  out_cap, d_out_lens, d_consumed, d_status, st);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     const bool wide = tuned && aec_wide_ok(m, out_cap) && ((uintptr_t)d_out_sym & 3) == 0 && (out_stride & 3) == 0 &&
                       out_stride >= scl_round_up(out_cap, 4);
@@ -752,13 +752,13 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
         aec_sparse_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                                  d_out_lens, d_consumed, d_status, (u32 *)d_scratch, st);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     if (wide) {
         aec_wide_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                                d_out_lens, d_consumed, d_status, (u32 *)d_scratch, st);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     const u32 threads = 256;
     const u32 blocks = (u32)((n_chunks + threads - 1) / threads);
@@ -785,7 +785,7 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
                            d_consumed, d_status, (u32 *)d_scratch, (u64 *)nullptr);
     } while (0);
     SCL_HIP_TRY(hipGetLastError());
-    return relay.out_end();
+    return relay.out_end(d_out_lens);
 }
 
 // ---- coder state carried across blocks (quirk Q4) -----------------------------------------------------------

@@ -409,10 +409,8 @@ void aec_fast_encode_launch(const scl_aec_model *m, const u8 *d_sym, u64 sym_str
                             u32 *d_status, hipStream_t st) {
     // round 3: the two-role encoder (scl_aec_split.hip) serves every batch; SCL_AEC_ENC=lane keeps the one-lane-per-
     // chunk kernel below for A/B timing and as a second implementation the tests compare against
-    static const bool lane_kernel = [] {
-        const char *e = getenv("SCL_AEC_ENC");
-        return e && (e[0] == 'l' || e[0] == 'L');
-    }();
+    const char *enc_env = getenv("SCL_AEC_ENC");  // read at every call, like the other switches
+    const bool lane_kernel = enc_env && (enc_env[0] == 'l' || enc_env[0] == 'L');
     if (!lane_kernel) {
         (void)aec_split_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride,
                                       d_out_bit_offset, d_out_nbits, d_status, st);

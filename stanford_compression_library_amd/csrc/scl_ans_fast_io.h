@@ -620,7 +620,8 @@ struct AnsBitReader {
         // Every line but the buffer's last is readable as a whole: ONE comparison and eight loads off one address.  (Eight
         // separately bounds-checked loads -- compare, zero default, branch, each -- were 70 instructions per line, a fifth
         // of the rANS decoder's vector instructions.)
-        if (j * 8 + 8 <= n_blocks16) {
+        // (not for ZERO_PAST_END users: the static-model arithmetic decoder sits at its register limit and spills with it)
+        if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) pf[i] = p[i];
@@ -780,7 +781,8 @@ struct AnsBitReaderW {
         // Every line but the buffer's last is readable as a whole: ONE comparison and eight loads off one address.  (Eight
         // separately bounds-checked loads -- compare, zero default, branch, each -- were 70 instructions per line, a fifth
         // of the rANS decoder's vector instructions.)
-        if (j * 8 + 8 <= n_blocks16) {
+        // (not for ZERO_PAST_END users: the static-model arithmetic decoder sits at its register limit and spills with it)
+        if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) pf[i] = p[i];

@@ -68,12 +68,12 @@ struct RowRelay {
     hipStream_t st = nullptr;
     u8 *user_out = nullptr;  // decode side: where the rows go back to
     u64 user_stride = 0, stride = 0, n_rows = 0;
-    u32 row_bytes = 0;
+    u32 row_bytes = 0, sym_bytes = 1;
     // encode side: d_sym / sym_stride are replaced by an aligned copy when they are not aligned
     int in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks, hipStream_t stream);
     // decode side: d_out / out_stride are replaced by aligned scratch; out_end() copies the rows back
     int out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, hipStream_t stream);
-    int out_end();
+    int out_end(const u32 *d_out_lens);
     ~RowRelay();
 };
 static inline bool scl_rows_aligned(const void *p, u64 stride) { return (((uintptr_t)p | stride) & 15) == 0; }

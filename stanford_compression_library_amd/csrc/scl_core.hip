@@ -67,27 +67,32 @@ bool scl_force_generic(void) {
 }
 
 // dst[r * dst_stride + b] = src[r * src_stride + b] for b < row_bytes: four bytes per lane, no alignment assumed
+// (row_lens, when given: only the first min(row_lens[r], row_bytes) bytes of row r -- what a decoder really produced)
 __global__ void __launch_bounds__(256) relay_rows_kernel(u8 *__restrict__ dst, u64 dst_stride, const u8 *__restrict__ src,
-                                                        u64 src_stride, u32 row_bytes, u64 n_rows) {
+                                                        u64 src_stride, u32 row_bytes, u64 n_rows,
+                                                        const u32 *__restrict__ row_lens) {
     const u32 quads = (row_bytes + 3) / 4;
     const u64 total = n_rows * quads;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += (u64)gridDim.x * 256) {
         const u64 r = i / quads;
         const u32 b = (u32)(i - r * quads) * 4;
+        const u32 len = row_lens ? min(row_lens[r], row_bytes) : row_bytes;
+        if (b >= len) continue;
         const u8 *s = src + r * src_stride + b;
         u8 *d = dst + r * dst_stride + b;
-        const u32 n = min(4u, row_bytes - b);
+        const u32 n = min(4u, len - b);
         for (u32 j = 0; j < n; ++j) d[j] = s[j];
     }
 }
 
-static int relay_launch(u8 *dst, u64 dst_stride, const u8 *src, u64 src_stride, u32 row_bytes, u64 n_rows, hipStream_t st) {
+static int relay_launch(u8 *dst, u64 dst_stride, const u8 *src, u64 src_stride, u32 row_bytes, u64 n_rows, hipStream_t st,
+                        const u32 *row_lens = nullptr) {
     if (!n_rows || !row_bytes) return SCL_OK;
     const u64 total = n_rows * ((row_bytes + 3) / 4);
     u64 blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(relay_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, dst, dst_stride, src, src_stride, row_bytes,
-                       n_rows);
+                       n_rows, row_lens);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -103,10 +108,11 @@ int RowRelay::in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks,
     if (stride == 0) stride = 16;
     hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
     if (e != hipSuccess) {
+        // no scratch, no re-laying: the caller's rows stay as they are, which sends the call to the any-parameter kernels
+        // (they take any alignment and need no scratch) instead of failing it
         scratch = nullptr;
-        scl_set_error("re-laying unaligned symbol rows: hipMallocAsync(%llu) failed: %s",
-                      (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
-        return SCL_E_ALLOC;
+        (void)hipGetLastError();
+        return SCL_OK;
     }
     if (int rc = relay_launch(scratch, stride, d_sym, sym_stride, chunk_len, n_chunks, st)) return rc;
     d_sym = scratch;
@@ -119,11 +125,10 @@ int RowRelay::out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, 
     st = stream;
     stride = scl_round_up((u64)out_cap + 1, 16);
     hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
-    if (e != hipSuccess) {
+    if (e != hipSuccess) {  // as above: the any-parameter kernels store to the caller's rows directly
         scratch = nullptr;
-        scl_set_error("re-laying unaligned output rows: hipMallocAsync(%llu) failed: %s",
-                      (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
-        return SCL_E_ALLOC;
+        (void)hipGetLastError();
+        return SCL_OK;
     }
     user_out = d_out;
     user_stride = out_stride;
@@ -134,9 +139,11 @@ int RowRelay::out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, 
     return SCL_OK;
 }
 
-int RowRelay::out_end() {
+// d_out_lens: the decoder's per-row symbol counts (device).  Only those bytes go back: whatever else the scratch holds --
+// stale pool memory behind a row's symbols, the whole row of a chunk that failed -- never reaches the caller's buffer.
+int RowRelay::out_end(const u32 *d_out_lens) {
     if (!user_out) return SCL_OK;
-    return relay_launch(user_out, user_stride, scratch, stride, row_bytes, n_rows, st);
+    return relay_launch(user_out, user_stride, scratch, stride, row_bytes * sym_bytes, n_rows, st, d_out_lens);
 }
 
 RowRelay::~RowRelay() {

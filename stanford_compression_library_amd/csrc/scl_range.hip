@@ -298,7 +298,7 @@ extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d
                            d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
                            d_out_lens, d_consumed, d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return relay.out_end();
+    return relay.out_end(d_out_lens);
 }
 
 // ---- uint16 symbol indices: alphabets up to 65536 (any model; the any-parameter kernels) ---------------------

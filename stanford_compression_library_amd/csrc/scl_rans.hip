@@ -260,6 +260,17 @@ extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info)
     return SCL_OK;
 }
 
+// Which encoder a batch of n_chunks equally long, 16-byte aligned rows would run with the calling thread's current
+// settings: 'L' / 'S' = the NUM_BITS_OUT = 1 tuned kernels with the 256-byte-ring / slot-ring writer, 'B' = the tuned
+// kernels for NUM_BITS_OUT > 1, 'G' = the any-parameter kernels.  For tests and tools (which switch the writer with
+// SCL_RANS_ENC_WRITER and want to know that the switch took).
+extern "C" int scl_rans_encoder_kind(const scl_rans_model *m, uint64_t n_chunks) {
+    if (!m) return 0;
+    if (scl_force_generic()) return 'G';
+    if (m->fast) return rf_use_slot_writer(m, n_chunks) ? 'S' : 'L';
+    return m->fastb ? 'B' : 'G';
+}
+
 extern "C" uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols) {
     if (!m) return 0;
     const u64 bits = (u64)m->dev.size_bits + m->dev.nsb + n_symbols * (u64)m->max_bits_per_symbol;
@@ -343,7 +354,7 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
                            d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens, d_consumed,
                            d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return relay.out_end();
+    return relay.out_end(d_out_lens);
 }
 
 // ---- uint16 symbol indices: alphabets up to 65536 (any model; the any-parameter kernels) -------------------

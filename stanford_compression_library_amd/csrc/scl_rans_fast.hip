@@ -626,8 +626,8 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
 // e.g. 513..768 workgroups (131 073..196 608 chunks: 0.467 -> 0.427 ms) -- and never for tables that drive the lanes in
 // lockstep.  1 024 workgroups (the headline batch) are two full rounds of L.  SCL_RANS_ENC_WRITER=L|S overrides (tests,
 // tools/ab_s.sh).
-static bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks) {
-    static const char *force = getenv("SCL_RANS_ENC_WRITER");
+bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks) {
+    const char *force = getenv("SCL_RANS_ENC_WRITER");  // read at every call: a test may switch it inside one process
     if (force && (force[0] == 'L' || force[0] == 'l')) return false;
     if (force && (force[0] == 'S' || force[0] == 's')) return true;
     if (m->enc_lockstep) return false;

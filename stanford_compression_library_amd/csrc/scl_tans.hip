@@ -436,13 +436,13 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
         rans_fast_decode_launch(m->rans, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     if (fast_ok) {
         tans_fast_decode_launch(m, d_in, in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride,
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
-        return relay.out_end();
+        return relay.out_end(d_out_lens);
     }
     SCL_REQUIRE(m->tables, "tans_decode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned buffers");
@@ -454,7 +454,7 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                        in_size_bytes, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,
                        d_consumed, d_status);
     SCL_HIP_TRY(hipGetLastError());
-    return relay.out_end();
+    return relay.out_end(d_out_lens);
 }
 
 // ---- uint16 symbol indices: alphabets up to 65536 (lookup tables in device memory) --------------------------

@@ -93,7 +93,11 @@ def test_outputs_stay_inside_their_buffers(name, shape, monkeypatch):
     writers = ["L", "S"] if name.startswith("rans_t") or name == "rans_total32" else [""]
     for wsel in writers:
         if wsel:
+            # the library reads the variable at every call (it used to cache it: ADVICE r3) -- and says which writer a
+            # batch of this size would get, so the switch is known to have taken
             monkeypatch.setenv("SCL_RANS_ENC_WRITER", wsel)
+            if not any_par:
+                assert chr(lib.load().scl_rans_encoder_kind(model._h, n_chunks)) == wsel
         for t in (enc.data, enc.bit_offset, enc.nbits, enc.status, *dec):
             t.view(torch.uint8).fill_(FILL)
         if any_par:
