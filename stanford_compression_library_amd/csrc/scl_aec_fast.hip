@@ -247,15 +247,51 @@ __global__ void __launch_bounds__(AF_THREADS)
     if (status) status[chunk] = st;
 }
 
+// ---- decoder (round 4) ---------------------------------------------------------------------------------------------
+// Its own table layout: a context row is 16 u16 INCLUSIVE cumulative counts Y[j] = count[0] + .. + count[j] (entries past
+// the alphabet hold the total, so Y[15] IS the row total: no separate total array, no second LDS update, no clamp of the
+// searched symbol).  c = Y[s-1] (0 for s = 0), d = Y[s]; update_model is Y[j] += 1 for j >= s = eight v_pk_add_u16 with a
+// mask row from the 512-byte LUT; the search max{s : c[s] <= target} is 16 - #{j : Y[j] > target}.
+// Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
+// back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
+// did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
+#define AD_OUT_BASE AF_TABLE_BYTES                 // [thread][64 bytes]
+#define AD_OUT_BYTES (AF_THREADS * 64)
+#define AD_LUT_BASE (AD_OUT_BASE + AD_OUT_BYTES)   // LUT[s][j] = (j >= s)
+#define AD_LDS_BYTES (AD_LUT_BASE + 512)
+
+__device__ __forceinline__ void ad_setup_tables(char *lds, const AecFastDev &P, u32 tid) {
+    if (tid < 128) {
+        const u32 s = tid >> 3, r = tid & 7;  // register r holds elements 2r, 2r+1
+        const u32 v = ((2 * r >= s) ? 1u : 0u) | ((2 * r + 1 >= s) ? 0x10000u : 0u);
+        *reinterpret_cast<u32_lds *>(lds + AD_LUT_BASE + s * 32 + r * 4) = v;
+    }
+    // inclusive from the exclusive initX: Y[j] = X[j + 1], Y[15] = total
+    u32 y[8];
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 lo = P.initX[r] >> 16;                                   // X[2r + 1]
+        const u32 hi = (r < 7) ? (P.initX[r + 1] & 0xFFFFu) : P.total0;    // X[2r + 2]
+        y[r] = lo | (hi << 16);
+    }
+    const uint4 a = make_uint4(y[0], y[1], y[2], y[3]);
+    const uint4 b = make_uint4(y[4], y[5], y[6], y[7]);
+    for (u32 c = 0; c < P.nctx; ++c) {
+        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32) = a;
+        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32 + 16) = b;
+    }
+    __syncthreads();
+}
+
 template <bool ORDER1>
 __global__ void __launch_bounds__(AF_THREADS)
     aec_fast_decode_kernel(AecFastDev P, const u8 *__restrict__ in, u64 in_size_bytes,
                            const u64 *__restrict__ bit_off, const u32 *__restrict__ in_nbits, u64 n_chunks,
                            u8 *__restrict__ out_sym, u64 out_stride, u32 out_cap, u32 *__restrict__ out_lens,
                            u32 *__restrict__ consumed, u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char lds[AF_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[AD_LDS_BYTES];
     const u32 tid = threadIdx.x;
-    af_setup_tables(lds, P, tid);
+    ad_setup_tables(lds, P, tid);
     const u64 chunk = (u64)blockIdx.x * AF_THREADS + tid;
     if (chunk >= n_chunks) return;
     const u32 nbits = in_nbits[chunk];
@@ -277,16 +313,17 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (status) status[chunk] = st;
         return;
     }
-    u32 *dst = reinterpret_cast<u32 *>(out_sym + chunk * out_stride);
+    u8 *dst = out_sym + chunk * out_stride;
+    char *ostage = lds + AD_OUT_BASE + tid * 64;
     u64 used = 32;
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
     AfRow R = af_row_load(lds, tid * 32);
-    u32 T = P.total0;
     u32 oword = 0;
     for (u32 i = 0;; ++i) {
         // ---- decode_step_core, :177-201 ----
+        const u32 T = R.b.w >> 16;  // Y[15]
         const double xT = af_recip((double)T);  // independent of the search below
         const double xr = af_recip((double)(hm - low) + 1.0);
         // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip), clamped for corrupt streams
@@ -304,32 +341,49 @@ __global__ void __launch_bounds__(AF_THREADS)
         acc0 = af_pk_count_gt(acc0, tp, R.b.z);
         acc1 = af_pk_count_gt(acc1, tp, R.b.w);
         const u32 acc = af_pk_add(acc0, acc1);
-        // s = #{j >= 1 : X[j] <= target} = 15 - #{X[j] > target}   (X[0] = 0 always counts)
-        u32 s = 15u + (u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16);
-        s = min(s, P.K - 1);
+        // s = #{j : Y[j] <= target} = 16 - #{Y[j] > target}; Y[15] = T > target, so s <= 15, and entries past the alphabet
+        // hold T as well, so s <= K - 1
+        const u32 s = 16u + (u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16);
         const u32 rowbase = ctx * AF_CTX_BYTES + tid * 32;
-        const u32 totaddr = AF_TOT_BASE + ctx * (AF_THREADS * 4) + tid * 4;
+        // c = Y[s - 1], d = Y[s]: one aligned-to-2 pair of u16 reads; s = 0 reads the two bytes in front of the row and
+        // replaces them by 0
         const u32 ea = rowbase + 2 * s;
-        const u32 c = *reinterpret_cast<const u16_lds *>(lds + ea);
-        const u32 d_raw = *reinterpret_cast<const u16_lds *>(lds + ea + 2);
-        af_row_update(R, lds, rowbase, totaddr, s);  // update_model
+        const u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea - 2);
+        const u32 d = *reinterpret_cast<const u16_lds *>(lds + ea);
+        const u32 c = s ? c_raw : 0u;
+        {  // update_model: Y[j] += 1 for j >= s
+            const uint4 ia = *reinterpret_cast<const uint4_lds *>(lds + AD_LUT_BASE + s * 32);
+            const uint4 ib = *reinterpret_cast<const uint4_lds *>(lds + AD_LUT_BASE + s * 32 + 16);
+            *reinterpret_cast<uint4_lds *>(lds + rowbase) =
+                make_uint4(af_pk_add(R.a.x, ia.x), af_pk_add(R.a.y, ia.y), af_pk_add(R.a.z, ia.z), af_pk_add(R.a.w, ia.w));
+            *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) =
+                make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
+        }
         ctx = af_next_ctx<ORDER1>(P, ctx, s);
-        const u32 Tcur = T;
-        // next symbol's row and total: issued now, needed only after the arithmetic below
+        // next symbol's row: issued now, needed only after the arithmetic below
         R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
-        T = *reinterpret_cast<const u32_lds *>(lds + AF_TOT_BASE + ctx * (AF_THREADS * 4) + tid * 4);
-        const u32 d = (s == 15) ? Tcur : d_raw;
-        af_shrink(low, hm, c, d, Tcur, xT);
-        // ---- symbol out ----
+        af_shrink2(low, hm, c, d, xT);
+        // ---- symbol out: four to a word, sixteen words to a 64-byte sector ----
         oword |= s << (8 * (i & 3));
         if ((i & 3) == 3) {
-            dst[i >> 2] = oword;
+            *reinterpret_cast<u32_lds *>(ostage + ((i >> 2) & 15) * 4) = oword;
             oword = 0;
+            if ((i & 63) == 63) {
+                const uint4 q0 = *reinterpret_cast<const uint4_lds *>(ostage);
+                const uint4 q1 = *reinterpret_cast<const uint4_lds *>(ostage + 16);
+                const uint4 q2 = *reinterpret_cast<const uint4_lds *>(ostage + 32);
+                const uint4 q3 = *reinterpret_cast<const uint4_lds *>(ostage + 48);
+                uint4 *p = reinterpret_cast<uint4 *>(dst + (i - 63));
+                p[0] = q0;
+                p[1] = q1;
+                p[2] = q2;
+                p[3] = q3;
+            }
         }
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
-        u32 k, m;
-        const bool edge = af_renorm_counts(low, hm, k, m);
+        u32 k, m, nlow, nhm;
+        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -360,12 +414,19 @@ __global__ void __launch_bounds__(AF_THREADS)
             const u32 bits = rd.get(kt);
             const u32 keep = (state << k) & AF_HALF;
             state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
-            low = (low << kt) & 0x7FFFFFFFu;
-            hm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+            low = nlow;
+            hm = nhm;
             used += kt;
         }
     }
-    if ((n & 3) != 0) dst[(n - 1) >> 2] = oword;  // last, partial word (zero-padded inside the row)
+    // the words of the last, incomplete sector (and the partial word, zero-padded inside the row)
+    {
+        const u32 done = n & ~63u;  // symbols already stored
+        u32 *d32 = reinterpret_cast<u32 *>(dst + done);
+        const u32 full = (n - done) >> 2;
+        for (u32 w = 0; w < full; ++w) d32[w] = *reinterpret_cast<const u32_lds *>(ostage + w * 4);
+        if ((n & 3) != 0) d32[full] = oword;
+    }
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;
     u32 e = 0;
