@@ -313,14 +313,13 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (status) status[chunk] = st;
         return;
     }
-    u8 *dst = out_sym + chunk * out_stride;
-    char *ostage = lds + AD_OUT_BASE + tid * 64;
+    AfSymOut so;
+    so.init(lds + AD_OUT_BASE, tid, out_sym + chunk * out_stride);
     u64 used = 32;
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
     AfRow R = af_row_load(lds, tid * 32);
-    u32 oword = 0;
     for (u32 i = 0;; ++i) {
         // ---- decode_step_core, :177-201 ----
         const u32 T = R.b.w >> 16;  // Y[15]
@@ -363,23 +362,7 @@ __global__ void __launch_bounds__(AF_THREADS)
         // next symbol's row: issued now, needed only after the arithmetic below
         R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
         af_shrink2(low, hm, c, d, xT);
-        // ---- symbol out: four to a word, sixteen words to a 64-byte sector ----
-        oword |= s << (8 * (i & 3));
-        if ((i & 3) == 3) {
-            *reinterpret_cast<u32_lds *>(ostage + ((i >> 2) & 15) * 4) = oword;
-            oword = 0;
-            if ((i & 63) == 63) {
-                const uint4 q0 = *reinterpret_cast<const uint4_lds *>(ostage);
-                const uint4 q1 = *reinterpret_cast<const uint4_lds *>(ostage + 16);
-                const uint4 q2 = *reinterpret_cast<const uint4_lds *>(ostage + 32);
-                const uint4 q3 = *reinterpret_cast<const uint4_lds *>(ostage + 48);
-                uint4 *p = reinterpret_cast<uint4 *>(dst + (i - 63));
-                p[0] = q0;
-                p[1] = q1;
-                p[2] = q2;
-                p[3] = q3;
-            }
-        }
+        so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
         u32 k, m, nlow, nhm;
@@ -419,14 +402,7 @@ __global__ void __launch_bounds__(AF_THREADS)
             used += kt;
         }
     }
-    // the words of the last, incomplete sector (and the partial word, zero-padded inside the row)
-    {
-        const u32 done = n & ~63u;  // symbols already stored
-        u32 *d32 = reinterpret_cast<u32 *>(dst + done);
-        const u32 full = (n - done) >> 2;
-        for (u32 w = 0; w < full; ++w) d32[w] = *reinterpret_cast<const u32_lds *>(ostage + w * 4);
-        if ((n & 3) != 0) d32[full] = oword;
-    }
+    so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;
     u32 e = 0;

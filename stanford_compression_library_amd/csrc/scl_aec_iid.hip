@@ -26,7 +26,9 @@
 #define AI_IC_BASE AI_ROW_BYTES                 // XB row first, then 16 block rows
 #define AI_LUT_GE_BASE (17 * AI_ROW_BYTES)      // mask rows (j >= w)
 #define AI_LUT_GT_BASE (AI_LUT_GE_BASE + 512)   // mask rows (j > b)
+#define AI_OUT_BASE (AI_LUT_GT_BASE + 512)      // decoder: 64 bytes of symbol staging per lane (AfSymOut)
 #define AI_LDS_BYTES (AI_LUT_GT_BASE + 512)
+#define AI_DEC_LDS_BYTES (AI_OUT_BASE + AI_THREADS * 64)
 
 struct AecIidDev {
     u32 K, total0;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(AI_THREADS)
                           const u32 *__restrict__ in_nbits, u64 n_chunks, u8 *__restrict__ out_sym, u64 out_stride,
                           u32 out_cap, u32 *__restrict__ out_lens, u32 *__restrict__ consumed,
                           u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char lds[AI_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[AI_DEC_LDS_BYTES];
     const u32 tid = threadIdx.x;
     ai_setup_tables(lds, P, tid);
     const u64 chunk = (u64)blockIdx.x * AI_THREADS + tid;
@@ -240,7 +242,8 @@ __global__ void __launch_bounds__(AI_THREADS)
         if (status) status[chunk] = st;
         return;
     }
-    u32 *dst = reinterpret_cast<u32 *>(out_sym + chunk * out_stride);
+    AfSymOut so;
+    so.init(lds + AI_OUT_BASE, tid, out_sym + chunk * out_stride);
     u64 used = 32;
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
@@ -249,7 +252,6 @@ __global__ void __launch_bounds__(AI_THREADS)
     XB.a = *reinterpret_cast<const uint4_lds *>(lds + tid * 32);
     XB.b = *reinterpret_cast<const uint4_lds *>(lds + tid * 32 + 16);
     const u32 last_block = (P.K - 1) >> 4;
-    u32 oword = 0;
     for (u32 i = 0;; ++i) {
         // ---- decode_step_core, :177-201 ----
         const double xT = af_recip((double)T);
@@ -285,12 +287,7 @@ __global__ void __launch_bounds__(AI_THREADS)
         *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
         af_shrink2(low, hm, c, d, xT);
         T += 1;
-        // ---- symbol out ----
-        oword |= s << (8 * (i & 3));
-        if ((i & 3) == 3) {
-            dst[i >> 2] = oword;
-            oword = 0;
-        }
+        so.put(s, i);  // symbol out: whole 64-byte sectors (AfSymOut)
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
         u32 k, m, nlow, nhm;
@@ -330,7 +327,7 @@ __global__ void __launch_bounds__(AI_THREADS)
             used += kt;
         }
     }
-    if ((n & 3) != 0) dst[(n - 1) >> 2] = oword;  // last, partial word (zero-padded inside the row)
+    so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;
     u32 e = 0;

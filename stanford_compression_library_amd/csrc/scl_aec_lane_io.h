@@ -123,3 +123,44 @@ struct AfReader {
     }
 };
 
+// ---- decoded symbols: four to a word, sixteen words to a 64-byte sector staged in LDS ([thread][64 bytes]), stored as four
+// back-to-back 16-byte stores.  One 4-byte store per four symbols -- what these kernels did until round 4 -- is not merged by
+// the memory system at 262 144 open output lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, r03).
+// `i` is the symbol's index in its chunk: the same for every live lane of the wave (the decode loops run in lockstep), so
+// the sector branch is wave-uniform.
+struct AfSymOut {
+    char *stage;
+    u8 *dst;
+    u32 oword;
+    __device__ __forceinline__ void init(char *lds_stage, u32 tid, u8 *row) {
+        stage = lds_stage + tid * 64;
+        dst = row;
+        oword = 0;
+    }
+    __device__ __forceinline__ void put(u32 s, u32 i) {
+        oword |= s << (8 * (i & 3));
+        if ((i & 3) == 3) {
+            *reinterpret_cast<u32_lds *>(stage + ((i >> 2) & 15) * 4) = oword;
+            oword = 0;
+            if ((i & 63) == 63) {
+                const uint4 q0 = *reinterpret_cast<const uint4_lds *>(stage);
+                const uint4 q1 = *reinterpret_cast<const uint4_lds *>(stage + 16);
+                const uint4 q2 = *reinterpret_cast<const uint4_lds *>(stage + 32);
+                const uint4 q3 = *reinterpret_cast<const uint4_lds *>(stage + 48);
+                uint4 *p = reinterpret_cast<uint4 *>(dst + (i - 63));
+                p[0] = q0;
+                p[1] = q1;
+                p[2] = q2;
+                p[3] = q3;
+            }
+        }
+    }
+    // the words of the last, incomplete sector and the partial word (zero-padded inside the row); n = symbols put
+    __device__ __forceinline__ void finish(u32 n) {
+        const u32 done = n & ~63u;
+        u32 *d32 = reinterpret_cast<u32 *>(dst + done);
+        const u32 full = (n - done) >> 2;
+        for (u32 w = 0; w < full; ++w) d32[w] = *reinterpret_cast<const u32_lds *>(stage + w * 4);
+        if ((n & 3) != 0) d32[full] = oword;
+    }
+};
