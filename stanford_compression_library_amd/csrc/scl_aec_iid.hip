@@ -81,15 +81,15 @@ __global__ void __launch_bounds__(AI_THREADS)
     aec_iid_encode_kernel(AecIidDev P, const u8 *__restrict__ sym, u64 sym_stride, const u32 *__restrict__ lens,
                           u32 chunk_len, u64 n_chunks, u8 *__restrict__ out, u64 out_stride,
                           u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits, u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char lds[AI_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[AI_DEC_LDS_BYTES];  // tables + 64 bytes of stream staging per lane
     const u32 tid = threadIdx.x;
     ai_setup_tables(lds, P, tid);
     const u64 chunk = (u64)blockIdx.x * AI_THREADS + tid;
     if (chunk >= n_chunks) return;
     const u32 n = lens ? lens[chunk] : chunk_len;
     const u32 *src = reinterpret_cast<const u32 *>(sym + chunk * sym_stride);
-    AfWriter wr;
-    wr.init(out + chunk * out_stride);
+    AfWriterT<true> wr;
+    wr.init(out + chunk * out_stride, lds + AI_OUT_BASE, tid);
     wr.put(P.size_bits < 32 ? (n & ((1u << P.size_bits) - 1u)) : n, P.size_bits);  // header, :92-99
     u32 st = (P.size_bits < 32 && (n >> P.size_bits)) ? SCL_ST_SIZE : 0u;
     u32 low = 0, hm = 0xFFFFFFFFu, pending = 0;

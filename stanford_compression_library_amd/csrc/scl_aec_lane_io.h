@@ -30,17 +30,41 @@ __device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
 
 // ---- forward bit writer: completed big-endian words go straight to the slot (4-byte stores; the stream is a
 // third of the input and L2 merges them -- a register FIFO costs ~50 phi copies per symbol, an LDS ring does not fit)
-struct AfWriter {
+// STAGED (round 4): completed words collect in 64 bytes of LDS per lane ([thread][64 bytes] at `lds_stage`) and leave as
+// whole 64-byte sectors, four back-to-back 16-byte stores -- for kernels that have the 16 KiB to spare.
+template <bool STAGED = false>
+struct AfWriterT {
     u32 hi;    // pending bits, right-aligned (the oldest is the most significant), < 32 of them
     u32 nacc;  // number of pending bits
     u32 *dst;
     u32 nwords;
+    char *stage;
 
-    __device__ __forceinline__ void init(u8 *slot) {
+    __device__ __forceinline__ void init(u8 *slot, char *lds_stage = nullptr, u32 tid = 0) {
         hi = 0;
         nacc = 0;
         nwords = 0;
         dst = reinterpret_cast<u32 *>(slot);
+        stage = STAGED ? lds_stage + tid * 64 : nullptr;
+    }
+    __device__ __forceinline__ void emit(u32 word_be) {
+        if (!STAGED) {
+            dst[nwords++] = word_be;
+            return;
+        }
+        *reinterpret_cast<u32_lds *>(stage + (nwords & 15u) * 4) = word_be;
+        ++nwords;
+        if ((nwords & 15u) == 0) {
+            const uint4 q0 = *reinterpret_cast<const uint4_lds *>(stage);
+            const uint4 q1 = *reinterpret_cast<const uint4_lds *>(stage + 16);
+            const uint4 q2 = *reinterpret_cast<const uint4_lds *>(stage + 32);
+            const uint4 q3 = *reinterpret_cast<const uint4_lds *>(stage + 48);
+            uint4 *p = reinterpret_cast<uint4 *>(dst + (nwords - 16));
+            p[0] = q0;
+            p[1] = q1;
+            p[2] = q2;
+            p[3] = q3;
+        }
     }
     __device__ __forceinline__ void put(u32 v, u32 nb) {  // v < 2^nb, nb <= 32
         // 32-bit arithmetic on purpose: see AnsFwdWriter::put (scl_ans_fast_io.h)
@@ -51,7 +75,7 @@ struct AfWriter {
 #if AF_ABLATE == 1
             nwords++;
 #else
-            dst[nwords++] = __builtin_bswap32(word);
+            emit(__builtin_bswap32(word));
 #endif
             hi = v & ((1u << r) - 1u);
             nacc = r;
@@ -69,10 +93,13 @@ struct AfWriter {
     }
     __device__ __forceinline__ u64 finish() {
         const u64 total = (u64)nwords * 32 + nacc;
+        if (STAGED)  // the words of the last, incomplete sector
+            for (u32 w = nwords & ~15u; w < nwords; ++w) dst[w] = *reinterpret_cast<const u32_lds *>(stage + (w & 15u) * 4);
         if (nacc) dst[nwords] = __builtin_bswap32(hi << (32 - nacc));
         return total;
     }
 };
+typedef AfWriterT<false> AfWriter;
 
 // ---- forward bit reader: 4-byte loads, one word ahead; bits past the end of the stream read as 0 ---------------
 struct AfReader {

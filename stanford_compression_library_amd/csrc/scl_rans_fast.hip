@@ -107,6 +107,25 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh
     return k;
 }
 
+// NUM_BITS_OUT = b > 1 (round 4; b in {4, 8, 16}, at most 16 bits released per symbol).  shrink_state releases GROUPS of b
+// bits: k_lo groups at x = L, one more from x = thresh on (scl_rans_fast_b.hip has the derivation), so
+//   q0  = floor(x / (f 2^(b k_lo))) = mulhi(x, rcp) >> sh      exact for every x < 2^nsb with rcp = ceil(2^E / f),
+//                                                              E = nsb + ceil(log2 f), sh = E + b k_lo - 32 -- PER SYMBOL:
+//         k_lo is too coarse in b for one shift to serve every symbol, so the shift rides in the entry (a shift
+//         instruction reads the low five bits of its operand: no extraction)
+//   posb = b if q0 >= RF 2^b (one more group) else 0;  s = b k_lo + posb bits released;  q = q0 >> posb
+//   x   = (x >> s) + c + q (M - f)
+// Entry {rcp, M - f, c, sh | (b k_lo) << 8}; msh_rt = . | . | (r + b) << 16 | b << 24.
+template <typename EncOut>
+__device__ __forceinline__ u32 rf_encode_entry_b(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns bits released
+    const u32 q0 = rf_umulhi(x, e.rcp) >> e.k_lo;              // low five bits of the word = sh
+    const u32 posb = (q0 >> ((msh_rt >> 16) & 0xFFu)) ? (msh_rt >> 24) : 0u;
+    const u32 k = (e.k_lo >> 8) + posb;
+    o.push(x, k);
+    x = rf_mad24(q0 >> posb, e.mf, (x >> k) + e.c);
+    return k;
+}
+
 struct Entries4 {
     EncEntry e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
@@ -144,7 +163,7 @@ struct Entries4 {
 // on exit: the table reads of a word are issued one word ahead of their use, in program order, so that their LDS latency
 // (100+ clocks with the bank conflicts of a random symbol mix) runs under the arithmetic of the current word instead of
 // in front of it -- with two waves per SIMD there is nobody else to hide it.
-template <int CHECK_SYM, int MSH_T, int R_T, typename EncOut>
+template <int CHECK_SYM, int MSH_T, int R_T, int NB_T = 1, typename EncOut>
 __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 &pre, u32 &x, EncOut &o, u32 &bad, u32 chk_c,
                                             char *lds, const char *tab, u32 msh_rt) {
     const u32 wv[5] = {v.x, v.y, v.z, v.w, next_w};
@@ -163,11 +182,12 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
-        const u32 k0 = rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o);
-        const u32 k1 = rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o);
+        // (a pair releases at most 26 bits for NUM_BITS_OUT = 1 and at most 32 for b > 1: the window holds 32 + 32)
+        const u32 k0 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o) : rf_encode_entry_b(x, cur.e[0], msh_rt, o);
+        const u32 k1 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o) : rf_encode_entry_b(x, cur.e[1], msh_rt, o);
         o.template check<RF_RING_OFF>(lds, k0 + k1);
-        const u32 k2 = rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o);
-        const u32 k3 = rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o);
+        const u32 k2 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o) : rf_encode_entry_b(x, cur.e[2], msh_rt, o);
+        const u32 k3 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o) : rf_encode_entry_b(x, cur.e[3], msh_rt, o);
         o.template check<RF_RING_OFF>(lds, k2 + k3);
     }
 }
@@ -175,7 +195,7 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
 #ifndef RF_WAVES_ATTR
 #define RF_WAVES_ATTR
 #endif
-template <typename EncOut, int CHECK_SYM, int MSH_T, int R_T>
+template <typename EncOut, int CHECK_SYM, int MSH_T, int R_T, int NB_T = 1>
 __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
@@ -251,7 +271,7 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     // the line.)
 #define RF_ENCODE_LINE(L)                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
-        rf_encode16<CHECK_SYM, MSH_T, R_T>(L.v[i], i < 7 ? L.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt); \
+        rf_encode16<CHECK_SYM, MSH_T, R_T, NB_T>(L.v[i], i < 7 ? L.v[i + 1].x : 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt); \
         if ((i & EncOut::FLUSH_MASK) == EncOut::FLUSH_PHASE) RF_FLUSH();                                               \
     }
     // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a load
@@ -300,13 +320,14 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     for (; i + 16 <= n; i += 16) {  // ragged tail: whole 16-byte blocks, then single symbols
         const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
         pre.load(v.x, tab);
-        rf_encode16<CHECK_SYM, MSH_T, R_T>(v, 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
+        rf_encode16<CHECK_SYM, MSH_T, R_T, NB_T>(v, 0u, pre, x, o, bad, chk_c, lds, tab, msh_rt);
         RF_FLUSH();
     }
     for (; i < n; ++i) {
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
-        o.template check<RF_RING_OFF>(lds, rf_encode_entry<MSH_T, R_T>(x, *reinterpret_cast<const EncEntry *>(tab + a), msh_rt, o));
+        const EncEntry e1 = *reinterpret_cast<const EncEntry *>(tab + a);
+        o.template check<RF_RING_OFF>(lds, NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, e1, msh_rt, o) : rf_encode_entry_b(x, e1, msh_rt, o));
         if ((i & 15u) == 15u) RF_FLUSH();
     }
     RF_FLUSH();
@@ -349,9 +370,24 @@ struct RfGenM {  // run-time constants of the any-total decoder
     u32 m, l;
 };
 // `lk` is updated to the lookahead that remains after the symbol (bits are consumed from its top).
-template <int ML_T, int CB_T>
+template <int ML_T, int CB_T, int NB_T = 1>
 __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, const char *tab, u32 ml_rt, u32 cb_rt,
                                                 const RfGenM &rf_gen) {
+    if (NB_T != 1) {
+        // NUM_BITS_OUT = b in {4, 8, 16} (round 4): expand_state (rANS.py:251-260) reads GROUPS of b bits while x < L.  The
+        // state is carried as X = x << 3 | three don't-care bits, like the literal b = 1 form below (nsb <= 29); d =
+        // bit_width(L) - bit_width(xn) = clz(xn) - cbl bits are missing (d >= 1 - b: xn < 2^nsb), i.e. sh = (d + b - 1) &
+        // ~(b - 1) bits are read, and the 64-bit shift that renormalises AND re-aligns is by sh + 3 = (that) | 3 (b >= 4:
+        // the low two bits of sh are zero): v_add + v_and_or.  rf_gen.m = b - 1 - cbl, rf_gen.l = ~(b - 1), ml_rt = m.
+        const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ml_rt) - 1u) << 3)));
+        const u32 xn = __umul24(x >> (ml_rt + 3), e.x) + e.y;
+        const u32 cl = (((u32)__builtin_clz(xn) + rf_gen.m) & rf_gen.l) | 3u;
+        const u64 t = ((((u64)xn) << 32) | lk) << cl;
+        x = (u32)(t >> 32);
+        lk = __builtin_amdgcn_alignbit(x, (u32)t, 3);
+        used = cl;
+        return e.x;
+    }
     if (ML_T > 0 && CB_T == 3) {
         // Top-aligned state X = x << 3 | three bits of lookahead (don't care): one 64-bit shift of xn:lookahead by
         // cl = clz(xn) renormalises; its high word is the new X, its low word the lookahead shifted by cl -- three bits
@@ -401,7 +437,7 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, cons
 // a check that found 17 words ahead and did nothing still leaves 4); the line loop asks after every second block,
 // because a check costs the wave BOTH refill bodies (some lane is always at either stage: 2 x 16 byte swaps and ring
 // writes, plus the loads) whether or not a given lane needed one.
-template <int ML_T, int CB_T, bool REFILL = true, typename DecIn>
+template <int ML_T, int CB_T, bool REFILL = true, int NB_T = 1, typename DecIn>
 __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const char *tab, u32 ml_rt, u32 cb_rt,
                                              const RfGenM &rf_gen) {
     u32 ow[4];
@@ -412,11 +448,12 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
         for (int h = 0; h < 2; ++h) {
             u32 lk = r.look(lds);
             u32 ua, ub;
-            const u32 ea = rf_decode_symbol<ML_T, CB_T>(x, lk, ua, tab, ml_rt, cb_rt, rf_gen);
-            const u32 eb = rf_decode_symbol<ML_T, CB_T>(x, lk, ub, tab, ml_rt, cb_rt, rf_gen);
-            // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead (the top-aligned variant reports clz, 3 more
-            // per symbol than it read)
-            r.advance(lds, (ML_T > 0 && CB_T == 3) ? ua + ub - 6u : ua + ub);
+            const u32 ea = rf_decode_symbol<ML_T, CB_T, NB_T>(x, lk, ua, tab, ml_rt, cb_rt, rf_gen);
+            const u32 eb = rf_decode_symbol<ML_T, CB_T, NB_T>(x, lk, ub, tab, ml_rt, cb_rt, rf_gen);
+            // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead (2 x 16 for NUM_BITS_OUT > 1: the second
+            // symbol's three don't-care bits are whatever follows); the top-aligned variants report their shift, 3 more
+            // per symbol than they read
+            r.advance(lds, ((ML_T > 0 && CB_T == 3) || NB_T != 1) ? ua + ub - 6u : ua + ub);
 #if RD_PERM_PAIRS
             // the symbol bytes of a pair with ONE v_perm (the earlier symbol is the more significant byte), the two pairs
             // of a word with another: three instead of four per four symbols
@@ -443,7 +480,7 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-template <int ML_T, int CB_T, int THREADS>
+template <int ML_T, int CB_T, int THREADS, int NB_T = 1>
 __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
@@ -463,7 +500,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
     const u32 M = P.M;
-    constexpr u32 XSH = (ML_T > 0 && CB_T == 3) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
+    constexpr u32 XSH = ((ML_T > 0 && CB_T == 3) || NB_T != 1) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
     for (u32 i = threadIdx.x; i < M; i += THREADS) {
         const uint2 v = P.d_dec_tab[i];
         reinterpret_cast<uint2 *>(s_lds)[i] = v;
@@ -493,22 +530,22 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     const u32 ml_rt = P.m_log2, cb_rt = 32 - P.nsb;
     RfGenM rf_gen;
     rf_gen.inv_m = 1.0 / (double)P.M;
-    rf_gen.m = P.M;
-    rf_gen.l = P.L;
+    rf_gen.m = NB_T != 1 ? P.dec_sadd : P.M;   // NUM_BITS_OUT > 1: b - 1 - cbl and ~(b - 1), see rf_decode_symbol
+    rf_gen.l = NB_T != 1 ? P.dec_notb : P.L;
     u8 *dst = out_sym + c * out_stride;
 
     // symbols come out last-first (rANS.py:291): the ragged head of the last 16-byte block ...
     u32 i = n;
     while (i & 15u) {
         u32 used, lk1 = r.look(lds);
-        const u32 e = rf_decode_symbol<ML_T, CB_T>(x, lk1, used, tab, ml_rt, cb_rt, rf_gen);
+        const u32 e = rf_decode_symbol<ML_T, CB_T, NB_T>(x, lk1, used, tab, ml_rt, cb_rt, rf_gen);
         r.advance(lds, used - XSH);
         dst[--i] = (u8)(e >> 24);
         if ((i & 3u) == 0) r.maybe_refill(lds);
     }
     // ... whole 16-byte blocks up to a line boundary ...
     while (i & 127u) {
-        const uint4 v = rf_decode16<ML_T, CB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
+        const uint4 v = rf_decode16<ML_T, CB_T, true, NB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 16;
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
@@ -521,8 +558,9 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
         uint4 a[8];
 #pragma unroll
         for (int b = 7; b >= 0; --b)
-            a[b] = (b & 1) ? rf_decode16<ML_T, CB_T, false>(x, r, lds, tab, ml_rt, cb_rt, rf_gen)
-                           : rf_decode16<ML_T, CB_T, true>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
+            // ring check every 32 symbols (<= 13 bits each), every 16 for NUM_BITS_OUT > 1 (<= 16 bits each)
+            a[b] = ((b & 1) && NB_T == 1) ? rf_decode16<ML_T, CB_T, false, NB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen)
+                                          : rf_decode16<ML_T, CB_T, true, NB_T>(x, r, lds, tab, ml_rt, cb_rt, rf_gen);
         i -= 128;
         if (cs.on) {
             cs.store(a, i);
@@ -550,9 +588,70 @@ static u32 ceil_log2_u32(u32 v) {
 
 // Decides whether the model qualifies and uploads the two tables.  Returns SCL_OK also when the model
 // simply does not qualify (m->fast stays 0).
+// NUM_BITS_OUT = b in {4, 8, 16} on the same kernels (round 4).  Qualifies: total a power of two <= 4096, RANGE_FACTOR =
+// 2^r, NUM_STATE_BITS = r + m + b <= 29 (state carried as x << 3), r + b <= 24 (quotients fit v_mad_u32_u24), at most 16
+// bits released per symbol (a pair of symbols fits the encoder's 32 + 32-bit window; 64 symbols fit its ring).
+static int rans_fast_build_tables_b(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum) {
+    const RansDev &D = m->dev;
+    const u32 b = D.b;
+    if (b != 4 && b != 8 && b != 16) return SCL_OK;
+    if (D.m_log2 == 0xFFFFFFFFu || D.M < 2 || D.M > 4096 || D.K < 2) return SCL_OK;
+    if ((D.RF & (D.RF - 1)) != 0 || D.nsb > 29 || m->max_bits_per_symbol > 16) return SCL_OK;
+    u32 r = 0;
+    while ((1ull << r) < D.RF) ++r;
+    if (r + b > 24 || D.nsb != r + D.m_log2 + b) return SCL_OK;
+    const u32 M = (u32)D.M, nsb = D.nsb;
+    std::vector<uint4> enc(256);
+    std::vector<uint2> dec(M);
+    for (u32 s = 0; s < 256; ++s) {
+        const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
+        const u32 f = h_freq[src], c = h_cum[src];
+        const u64 a1 = ((u64)D.RF * f) << b;  // max_shrunk_state + 1 (rANS.py:112)
+        u32 k_lo = 0, k_hi = 0;
+        while ((D.L >> (k_lo * b)) >= a1) ++k_lo;
+        while ((m->H >> (k_hi * b)) >= a1) ++k_hi;
+        if (k_hi > k_lo + 1 || (k_lo + 1) * b > 16) return SCL_OK;
+        // floor(x / (f 2^(b k_lo))) = (x rcp) >> (E + b k_lo) for every x < 2^nsb: rcp = ceil(2^E / f) with E = nsb +
+        // ceil(log2 f) (the error x (rcp f - 2^E) / (f 2^(E + b k_lo)) stays below 1 / (f 2^(b k_lo)))
+        const u32 E = nsb + ceil_log2_u32(f);
+        const u64 rcp = ((1ull << E) + f - 1) / f;
+        if ((rcp >> 32) != 0 || E + b * k_lo < 32 || E + b * k_lo - 32 > 31) return SCL_OK;
+        enc[s] = make_uint4((u32)rcp, M - f, c, (E + b * k_lo - 32) | ((b * k_lo) << 8));
+    }
+    for (u32 s = 0; s < D.K; ++s)
+        for (u32 j = 0; j < h_freq[s]; ++j) dec[h_cum[s] + j] = make_uint2(h_freq[s] | (s << 24), j);
+    hipError_t e = hipMalloc((void **)&m->d_enc_tab, 256 * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_dec_tab, M * sizeof(uint2));
+    if (e == hipSuccess) e = hipMemcpy(m->d_enc_tab, enc.data(), 256 * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_dec_tab, dec.data(), M * sizeof(uint2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        scl_set_error("rans_model_create: fast-path table upload failed: %s", hipGetErrorString(e));
+        return SCL_E_HIP;
+    }
+    m->enc_lockstep = 0;
+    m->fdev.K = D.K;
+    m->fdev.nsb = nsb;
+    m->fdev.size_bits = D.size_bits;
+    m->fdev.m_log2 = D.m_log2;
+    m->fdev.L = (u32)D.L;
+    m->fdev.M = M;
+    m->fdev.enc_msh = ((r + b) << 16) | (b << 24);
+    m->fdev.b = b;
+    const u32 cbl = 32 - scl_bit_width_u64(D.L);
+    m->fdev.dec_sadd = b - 1 - cbl;  // (mod 2^32: added to a count of leading zeros >= cbl - b + 1)
+    m->fdev.dec_notb = ~(b - 1);
+    m->fdev.d_enc_tab = m->d_enc_tab;
+    m->fdev.d_dec_tab = m->d_dec_tab;
+    m->fast = 1;
+    return SCL_OK;
+}
+
 int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum) {
     const RansDev &D = m->dev;
     m->fast = 0;
+    m->fdev.b = 1;
+    m->fdev.dec_sadd = m->fdev.dec_notb = 0;
+    if (D.b > 1) return rans_fast_build_tables_b(m, h_freq, h_cum);
     // any total 2 <= M <= 4096 (a power of two or not), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31
     if (D.b != 1 || D.M < 2 || D.M > 4096) return SCL_OK;
     if ((D.RF & (D.RF - 1)) != 0 || D.RF > (1u << 23) || D.nsb > 30 || D.K < 2) return SCL_OK;
@@ -662,6 +761,19 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
         else                                      \
             RF_LAUNCH_ENC_W(EncOutL, CHECK, MSH); \
     } while (0)
+    if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}: run-time constants, the symbol check that fits the alphabet
+#define RF_LAUNCH_ENC_B(OUT, CHECK)                                                                                     \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, 0, 0, 0>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
+                       d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
+        const int check = m->fdev.K == 256 ? 0 : (m->fdev.K <= 128 ? 1 : 2);
+        if (slots) {
+            if (check == 0) RF_LAUNCH_ENC_B(EncOutS, 0); else if (check == 1) RF_LAUNCH_ENC_B(EncOutS, 1); else RF_LAUNCH_ENC_B(EncOutS, 2);
+        } else {
+            if (check == 0) RF_LAUNCH_ENC_B(EncOutL, 0); else if (check == 1) RF_LAUNCH_ENC_B(EncOutL, 1); else RF_LAUNCH_ENC_B(EncOutL, 2);
+        }
+#undef RF_LAUNCH_ENC_B
+        return;
+    }
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
     if (m->fdev.K <= 128) {
         if (msh == 10) RF_LAUNCH_ENC(1, 10); else RF_LAUNCH_ENC(1, 0);
@@ -683,6 +795,18 @@ void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_siz
                        d_out_lens, d_consumed, d_status)
     // up to 2 x 256 small workgroups are resident at once (64 KiB of LDS each): beyond that the 1024-lane form wins
     const bool big = n_chunks > 2ull * 256 * RD_THREADS_SMALL;
+    if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}
+        if (big)
+            hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0, RD_THREADS, 0>), dim3((u32)((n_chunks + RD_THREADS - 1) / RD_THREADS)),
+                               dim3(RD_THREADS), 0, st, m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym,
+                               out_stride, out_cap, d_out_lens, d_consumed, d_status);
+        else
+            hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0, RD_THREADS_SMALL, 0>),
+                               dim3((u32)((n_chunks + RD_THREADS_SMALL - 1) / RD_THREADS_SMALL)), dim3(RD_THREADS_SMALL), 0, st,
+                               m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                               d_out_lens, d_consumed, d_status);
+        return;
+    }
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
     if (m->fdev.m_log2 == 0xFFFFFFFFu) {  // total is not a power of two
         if (big) RF_LAUNCH_DEC(-1, 0, RD_THREADS); else RF_LAUNCH_DEC(-1, 0, RD_THREADS_SMALL);

@@ -22,7 +22,11 @@ struct RansFastDev {
     u32 m_log2;     // log2(M) if M is a power of two, else 0xFFFFFFFF
     u32 L;
     u32 M;
-    u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 | r << 16 (rans_fast_build_tables)
+    u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 | r << 16 (rans_fast_build_tables);
+                    // NUM_BITS_OUT = b > 1: (r + b) << 16 | b << 24 (rf_encode_entry_b)
+    u32 b;          // NUM_BITS_OUT: 1, or 4 / 8 / 16 on the same kernels since round 4
+    u32 dec_sadd;   // b > 1: b - 1 - cbl, cbl = 32 - bit_width(L)   (rf_decode_symbol)
+    u32 dec_notb;   // b > 1: ~(b - 1)
     const uint4 *d_enc_tab;  // [256] {rcp, M-f, cum, k_lo}
     const uint2 *d_dec_tab;  // [M]   slot -> {f | sym << 24, slot - cum}
 };
