@@ -26,7 +26,8 @@
 // ---------------------------------------------------------------------------------------------------
 struct RgOut {
     u64 acc;   // pending bytes in memory order (byte j of the stream tail at bits [8j, 8j+8))
-    u32 cnt;   // number of pending bytes, < 4 between symbols
+    u32 cnt;   // number of pending BITS (a multiple of 8), < 32 between symbols -- bits, not bytes: every count on the
+               // per-symbol path is a shift amount, and 8 * bytes was an instruction each time (round 4)
     u32 ra;    // LDS byte address of the ring word written next
     u32 fa;    // LDS byte address of the oldest unflushed word
     u32 pend;  // completed words not yet in memory
@@ -49,16 +50,16 @@ struct RgOut {
         nfl = 0;
         slot = slot_;
     }
-    // append nb (0..4) bytes; byte j of `bytes` (bits [8j, 8j+8)) is the j-th byte in stream order
-    __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nb) {
-        acc |= (u64)bytes << (8 * cnt);
-        cnt += nb;
-        if (cnt >= 4) {
+    // append nbits / 8 (0..4) bytes; byte j of `bytes` (bits [8j, 8j+8)) is the j-th byte in stream order
+    __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nbits) {
+        acc |= (u64)bytes << cnt;
+        cnt += nbits;
+        if (cnt >= 32) {
             *reinterpret_cast<u32 *>(lds + ra) = (u32)acc;
             ra = (ra + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
             ++pend;
             acc >>= 32;
-            cnt -= 4;
+            cnt -= 32;
         }
     }
     // 16 pending words -> 64 contiguous bytes; call at least every 16 symbols (<= 16 new words, ring of 32)
@@ -105,9 +106,10 @@ struct RgOut {
         maybe_flush(lds);
         u32 *w32 = reinterpret_cast<u32 *>(slot);
         const u64 words = (u64)nfl + pend;
-        if (words * 4 + cnt > cap) {
+        const u32 cnt_bytes = cnt >> 3;
+        if (words * 4 + cnt_bytes > cap) {
             overflow = 1;
-            return words * 4 + cnt;
+            return words * 4 + cnt_bytes;
         }
         if (have_held) {  // counted in nfl already: bytes [4*(nfl-16), 4*nfl)
             uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
@@ -121,8 +123,8 @@ struct RgOut {
             w32[nfl + j] = *reinterpret_cast<const u32 *>(lds + a);
             a = (a + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
         }
-        for (u32 j = 0; j < cnt; ++j) slot[words * 4 + j] = (u8)(acc >> (8 * j));
-        return words * 4 + cnt;
+        for (u32 j = 0; j < cnt_bytes; ++j) slot[words * 4 + j] = (u8)(acc >> (8 * j));
+        return words * 4 + cnt_bytes;
     }
 };
 
@@ -154,7 +156,7 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
 }
 
 // shrink_range (:88-105) + normalize (:107-179) for one symbol; returns its released bytes (0..3 of them, first one in
-// the low byte).  The normalisation is a closed form: the loop first releases every leading byte on which low and
+// the low byte) and their number IN BITS.  The normalisation is a closed form: the loop first releases every leading byte on which low and
 // low + range agree (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them (range > 0, so
 // the two values differ and nb1 <= 3); it goes on only if the range left after that is below BOTTOM (the carry-less
 // reset, :136-178) -- rare.  ONE branch per symbol covers everything rare: the reference's literal loop, a symbol that
@@ -173,11 +175,11 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
         low0 = low + e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
         range0 = r * e.y;
     }
-    const u32 nb1 = (u32)__builtin_clz(low0 ^ (low0 + range0)) >> 3;
-    const u32 sh = 8 * nb1;
+    // 8 * (leading common bytes): clz & 0x18 (the two values differ, so clz <= 31 and the count <= 3 bytes)
+    const u32 sh = (u32)__builtin_clz(low0 ^ (low0 + range0)) & 0x18u;
     const u32 range_s = range0 << sh;
-    bytes = __builtin_bswap32(low0) & ((1u << sh) - 1u);
-    nb = nb1;
+    bytes = __builtin_amdgcn_ubfe(__builtin_bswap32(low0), 0, sh);  // the low sh bits (sh = 0: none)
+    nb = sh;  // in BITS
     low = low0 << sh;
     range = range_s;
     if (__builtin_expect(range_s < RG_BOTTOM, 0)) {
@@ -191,19 +193,19 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
             if (!settled && range >= RG_BOTTOM) break;
             if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
             bytes |= (low >> 24) << (8 * j);
-            ++nb;
+            nb += 8;
             low <<= 8;
             range <<= 8;
         }
-        if (nb == 4) {  // a whole word at once: everything goes out now, in the reference's order
+        if (nb == 32) {  // a whole word at once: everything goes out now, in the reference's order
             o.put_bytes(lds, pb, pn);
             pb = 0;
             pn = 0;
-            o.put_bytes(lds, bytes, 4);
+            o.put_bytes(lds, bytes, 32);
             bytes = 0;
             nb = 0;
             while (rg_needs_byte(low, range)) {  // never taken for valid models; keeps the loop exact
-                o.put_bytes(lds, low >> 24, 1);
+                o.put_bytes(lds, low >> 24, 8);
                 low <<= 8;
                 range <<= 8;
             }
@@ -222,7 +224,7 @@ struct RgLine128 {
 // table entry {c, f} of the symbol whose byte offset into the table is a (= symbol * 8); MODE 2 has no table
 template <int MODE>
 __device__ __forceinline__ uint2 rg_entry(const char *tab, u32 a) {
-    if (RG_UNI(MODE)) return make_uint2(a >> 3, 0u);
+    if (RG_UNI(MODE)) return make_uint2(a, 0u);  // a IS the symbol here (rg_encode16)
     return *reinterpret_cast<const uint2 *>(tab + a);
 }
 
@@ -233,18 +235,22 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const u32 w = wv[d];
-        const u32 a[4] = {(w << 3) & 0x7F8u, (w >> 5) & 0x7F8u, (w >> 13) & 0x7F8u, (w >> 21) & 0x7F8u};
+        // table offsets 8 * symbol; the table-free modes (256 symbols: nothing to check) take the symbol itself, one v_bfe
+        const u32 a[4] = {RG_UNI(MODE) ? __builtin_amdgcn_ubfe(w, 0, 8) : (w << 3) & 0x7F8u,
+                          RG_UNI(MODE) ? __builtin_amdgcn_ubfe(w, 8, 8) : (w >> 5) & 0x7F8u,
+                          RG_UNI(MODE) ? __builtin_amdgcn_ubfe(w, 16, 8) : (w >> 13) & 0x7F8u,
+                          RG_UNI(MODE) ? (w >> 24) : (w >> 21) & 0x7F8u};
         // two symbols per visit of the byte accumulator: their released bytes (0..3 each in the common case) are
         // merged first when they fit a word together -- "a word completed" is then tested, and its branch body
         // executed by the whole wave, once per pair instead of once per symbol
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
-            bad = max(bad, max(a[j], a[j + 1]));
-            u32 b0, n0, b1, n1, z0 = 0, zn = 0;
+            if (!RG_UNI(MODE)) bad = max(bad, max(a[j], a[j + 1]));
+            u32 b0, n0, b1, n1, z0 = 0, zn = 0;  // n0, n1: bits
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0, z0, zn, o, lds);
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1, b0, n0, o, lds);
-            if (n0 + n1 <= 4) {  // each <= 3
-                o.put_bytes(lds, b0 | (b1 << (8 * n0)), n0 + n1);
+            if (n0 + n1 <= 32) {  // each <= 24
+                o.put_bytes(lds, b0 | (b1 << n0), n0 + n1);
             } else {
                 o.put_bytes(lds, b0, n0);
                 o.put_bytes(lds, b1, n1);
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     const u8 *src = sym + c * sym_stride;
     RgOut o;
     o.init(threadIdx.x, out + c * out_stride, out_stride);
-    o.put_bytes(lds, __builtin_bswap32(n), 4);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
+    o.put_bytes(lds, __builtin_bswap32(n), 32);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
     u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
     RgDivM md;
     md.m_log2 = P.m_log2;
@@ -287,27 +293,42 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
 #pragma nounroll
     for (u32 t = 0; t < n_lines; ++t) {
         cur.load(src16 + 8 * t);
+        if (RG_UNI(MODE)) {
+            // half a line per iteration (round 4, the table-free modes: the two with a table spill in this form): the
+            // two-block form moves the line down by two registers after every 32 symbols (24 copies, 0.75 vector
+            // instructions per symbol); this one moves four registers once per line
 #pragma nounroll
-        for (int q = 0; q < 4; ++q) {
-            rg_encode16<MODE>(cur.v[0], low, range, o, bad, lds, tab, md);
-            rg_encode16<MODE>(cur.v[1], low, range, o, bad, lds, tab, md);
+            for (int q = 0; q < 2; ++q) {
+                rg_encode16<MODE>(cur.v[0], low, range, o, bad, lds, tab, md);
+                rg_encode16<MODE>(cur.v[1], low, range, o, bad, lds, tab, md);
+                rg_encode16<MODE>(cur.v[2], low, range, o, bad, lds, tab, md);
+                rg_encode16<MODE>(cur.v[3], low, range, o, bad, lds, tab, md);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
+                for (int i = 0; i < 4; ++i) cur.v[i] = cur.v[i + 4];
+            }
+        } else {
+#pragma nounroll
+            for (int q = 0; q < 4; ++q) {
+                rg_encode16<MODE>(cur.v[0], low, range, o, bad, lds, tab, md);
+                rg_encode16<MODE>(cur.v[1], low, range, o, bad, lds, tab, md);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cur.v[i] = cur.v[i + 2];
+            }
         }
     }
     u32 i = n_lines << 7;
     for (; i + 16 <= n; i += 16)
         rg_encode16<MODE>(*reinterpret_cast<const uint4 *>(src + i), low, range, o, bad, lds, tab, md);
     for (; i < n; ++i) {
-        const u32 a = (u32)src[i] << 3;
-        bad = max(bad, a);
+        const u32 a = RG_UNI(MODE) ? (u32)src[i] : (u32)src[i] << 3;
+        if (!RG_UNI(MODE)) bad = max(bad, a);
         u32 bytes, nb, z0 = 0, zn = 0;
         rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a), md, bytes, nb, z0, zn, o, lds);
         o.put_bytes(lds, bytes, nb);
         if ((i & 15u) == 15u) o.maybe_flush(lds);
     }
     o.maybe_flush(lds);
-    o.put_bytes(lds, __builtin_bswap32(low), 4);  // flush :181-186: the four bytes of low, most significant first
+    o.put_bytes(lds, __builtin_bswap32(low), 32);  // flush :181-186: the four bytes of low, most significant first
     const u64 total_bytes = o.finish(lds);
     out_bit_off[c] = c * out_stride * 8;
     out_nbits[c] = (u32)(total_bytes * 8);

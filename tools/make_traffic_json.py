@@ -25,7 +25,9 @@ def entry(pmc_path, bench_path, out_path):
                 vals.setdefault(side, {"kernel": m.group(1).strip()})[m.group(2)] = float(m.group(3))
     in_bytes = b["config"]["chunks_per_gpu"] * b["config"]["chunk_len"]
     stream_bytes = b["roofline_encode"]["algorithmic_bytes_per_launch"] - in_bytes
-    out = {"key": b["traffic_key"], "algorithmic_bytes_per_launch": b["roofline_encode"]["algorithmic_bytes_per_launch"]}
+    # csrc_sha: the kernel sources the pass was taken on (bench.py csrc_sha()); bench.py quotes an entry only for the same
+    out = {"key": b["traffic_key"], "csrc_sha": b.get("csrc_sha"),
+           "algorithmic_bytes_per_launch": b["roofline_encode"]["algorithmic_bytes_per_launch"]}
     for side, v in vals.items():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
