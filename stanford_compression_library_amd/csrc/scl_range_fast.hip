@@ -348,10 +348,18 @@ struct RgIn {  // forward bit reader over a per-lane LDS word ring (same scheme 
     u32 bias;
 
     __device__ __forceinline__ void load64(u64 j) {
+        // one bounds test for the whole 64-byte block (all but the buffer's last are readable whole): the four separately
+        // tested loads were 36 instructions per refill, run by the whole wave whenever any lane refills
+        if (j * 4 + 4 <= n_blocks16) {
+            const uint4 *p = base + j * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u64 idx = j * 4 + i;
-            pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) pf[i] = p[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 idx = j * 4 + i;
+                pf[i] = (idx < n_blocks16) ? base[idx] : make_uint4(0, 0, 0, 0);
+            }
         }
     }
     __device__ __forceinline__ void push_pf(char *lds) {
