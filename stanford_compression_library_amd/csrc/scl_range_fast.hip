@@ -268,7 +268,10 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
                                                                           u64 out_stride, u64 *__restrict__ out_bit_off,
                                                                           u32 *__restrict__ out_nbits,
                                                                           u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char s_lds[RGE_RING_BYTES + 256 * 8];
+    #ifndef RGE_LDS_PAD
+#define RGE_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
+#endif
+    __shared__ __attribute__((aligned(16))) char s_lds[RGE_RING_BYTES + 256 * 8 + RGE_LDS_PAD];
     char *lds = s_lds;
     const char *tab = s_lds + RGE_RING_BYTES;
     reinterpret_cast<uint2 *>(s_lds + RGE_RING_BYTES)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
