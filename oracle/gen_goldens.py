@@ -559,9 +559,32 @@ def gen_wide(col, rng):
                        lambda: ArithmeticEncoder(ap, mk()), lambda: ArithmeticDecoder(ap, mk()), rng)
 
 
+def gen_counts(col, rng):
+    """G12 (row f3): ``DataBlock.get_counts`` / ``get_empirical_distribution`` of the reference (core/data_block.py:37-94)
+    on byte blocks and on blocks over wider alphabets: the symbols that occur (sorted) and their counts, plus the
+    probabilities the reference derives from them.  What the device histograms (scl_histogram_u8 / _u16) must equal."""
+    cases = [("bytes_empty", 256, 0), ("bytes_1", 256, 1), ("bytes_17", 256, 17), ("bytes_4096", 256, 4096),
+             ("bytes_hot", 256, 100003), ("bytes_few", 7, 5000), ("u16_1000", 1000, 4097), ("u16_65536", 65536, 30001)]
+    for name, K, n in cases:
+        data = rng.integers(0, K, n)
+        if name == "bytes_hot":
+            data[: n // 2] = 7  # one symbol takes half the block
+        block = DataBlock(data.tolist())
+        counts = block.get_counts() if n else {}
+        syms = np.array(sorted(counts), dtype=np.int64)
+        cnt = np.array([counts[int(s)] for s in syms], dtype=np.int64)
+        probs = np.zeros(0)
+        if n:
+            pd = block.get_empirical_distribution().prob_dict
+            probs = np.array([pd[int(s)] for s in syms], dtype=np.float64)
+        assert int(cnt.sum()) == n
+        col.add(dict(kind="counts", group="G12", name=name, K=K, n=n),
+                data=data.astype(np.uint16 if K > 256 else np.uint8), symbols=syms, counts=cnt, probs=probs)
+
+
 def main(out_dir):
     for name, fn in (("rans", gen_rans), ("tans", gen_tans), ("range", gen_range), ("aec", gen_aec),
-                     ("stream", gen_stream), ("wide", gen_wide)):
+                     ("stream", gen_stream), ("wide", gen_wide), ("counts", gen_counts)):
         col = Collector()
         fn(col, np.random.default_rng(12345))
         col.save(f"{out_dir}/golden_{name}.npz")

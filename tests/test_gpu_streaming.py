@@ -94,6 +94,25 @@ def test_histogram_equals_get_counts():
 
 
 @pytest.mark.gpu
+def test_histograms_equal_reference_counts():
+    """row f3 against a REFERENCE-generated fixture (golden_counts.npz, group G12: the reference's own
+    ``DataBlock.get_counts`` on these blocks, core/data_block.py:37-94) -- not against this package's get_counts"""
+    from conftest import load_golden
+
+    backend_lib.require_device()
+    for case in load_golden("counts"):
+        data = case.arr("data")
+        want = np.zeros(case.K, dtype=np.int64)
+        want[case.arr("symbols")] = case.arr("counts")
+        if case.K <= 256:
+            got = histogram_u8(torch.from_numpy(data).cuda()) if case.n else np.zeros(256, dtype=np.int64)
+            assert np.array_equal(np.asarray(got)[:case.K], want) and int(np.asarray(got)[case.K:].sum()) == 0
+        else:
+            got = histogram_u16(torch.from_numpy(data.astype(np.uint16)).cuda(), case.K)
+            assert np.array_equal(np.asarray(got), want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [257, 1000, 16384, 16385, 65536])
 def test_histogram_u16_equals_get_counts(K):
     """alphabets above 256 symbols: LDS-private bins up to 16384 symbols, straight global atomics above"""

@@ -171,3 +171,19 @@ def test_normalize_counts_properties():
     assert normalize_counts([5, 0, 1, 94], 16).tolist() == [2, 0, 1, 13]
     fr = frequencies_from_counts([0, 3, 0, 1], 4)
     assert fr.freq_dict == {1: 3, 3: 1}
+
+
+def test_get_counts_equals_reference_fixture():
+    """row f3: ``DataBlock.get_counts`` / ``get_empirical_distribution`` against what the REFERENCE computed for the same
+    blocks (tests/golden/golden_counts.npz, group G12, written by oracle/gen_goldens.py from core/data_block.py:37-94)"""
+    from conftest import load_golden
+
+    for case in load_golden("counts"):
+        data = case.arr("data")
+        block = DataBlock(data.tolist())
+        counts = block.get_counts() if case.n else {}
+        assert sorted(counts) == case.arr("symbols").tolist()
+        assert [counts[s] for s in sorted(counts)] == case.arr("counts").tolist()
+        if case.n:
+            pd = block.get_empirical_distribution().prob_dict
+            assert np.allclose([pd[s] for s in sorted(pd)], case.arr("probs"), rtol=0, atol=1e-15)
