@@ -273,6 +273,14 @@ uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks);
 int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
                         uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
                         uint64_t *d_out_byte_offset, void *d_scratch, void *stream);
+/* (ABI version 5) the same with the first record at byte *d_base of d_out, d_base in DEVICE memory (NULL = 0); the offsets
+   written are absolute (entry 0 = *d_base, entry n = where the next record would start).  Sub-batch i + 1 of a batch passes
+   the address of sub-batch i's last offset entry (it may be the address its own entry 0 goes to): one dense buffer and one
+   offset table without the host ever learning a size -- so that a sub-batch can be compacted on a second stream while the
+   next one is still being encoded. */
+int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                           uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                           uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch, void *stream);
 
 /* ---- multi-GPU: variable-length gather of compacted streams over RCCL (SURVEY.md 8e, configs[4]) ------
  * No reference counterpart (the reference has no communication).  One process per GPU; every rank encodes and

@@ -493,3 +493,58 @@ def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     _lib.check(rc, "scl_streams_compact")
     tstream.synchronize()  # the stream the kernels were queued on: results readable, scratch reusable on return
     return out, offsets
+
+
+class DensePipeline:
+    """Encode a batch straight to DENSE streams (every chunk's ``BitArray.tobytes()`` back to back + int64 offsets[n + 1],
+    or the reference's framed file bytes) in sub-batches on two streams: the compaction of sub-batch i runs while sub-batch
+    i + 1 is still being encoded.  The encoders fill slots back to front and only know a stream's length at its end, so the
+    left-align / compaction pass is a second pass over the output whatever one does; what can be hidden is its time -- the
+    encoders are bound by instruction issue, the compaction by memory.  ``scl_streams_compact_at`` keeps the offsets on the
+    device (sub-batch i + 1 starts where sub-batch i ended), so nothing here waits for the host.
+
+    Buffers are owned by the object (worst-case sizes, reused across calls); results are valid once the caller's current
+    stream has passed the call.  Static-model coders only (rANS / tANS / range / FixedFreqModel: no per-call scratch)."""
+
+    def __init__(self, model, n_chunks: int, chunk_len: int, device, n_sub: int = 2, framed: bool = False):
+        import torch
+
+        assert not model._needs_scratch and not model.wide
+        self.model, self.n_chunks, self.chunk_len, self.framed = model, int(n_chunks), int(chunk_len), bool(framed)
+        n_sub = max(1, min(int(n_sub), self.n_chunks))
+        self.bounds = [self.n_chunks * i // n_sub for i in range(n_sub + 1)]
+        self.enc = model.alloc_encoded(self.n_chunks, self.chunk_len, device)
+        self.dense = torch.empty(compact_capacity(self.n_chunks, self.enc.stride, framed), dtype=torch.uint8, device=device)
+        self.offsets = torch.empty(self.n_chunks + 1, dtype=torch.int64, device=device)
+        per = max(b - a for a, b in zip(self.bounds, self.bounds[1:]))
+        self.scr = compact_scratch_bytes(per)
+        self.scratch = torch.empty(self.scr * n_sub, dtype=torch.uint8, device=device)
+        self.s_enc, self.s_cmp = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+
+    def run(self, sym):
+        """-> (dense uint8 tensor, int64 offsets [n + 1]); ``offsets[-1]`` bytes of ``dense`` are the streams"""
+        import torch
+
+        L = _lib.load()
+        dev = sym.device
+        assert sym.shape == (self.n_chunks, self.chunk_len) and sym.stride(1) == 1
+        cur = torch.cuda.current_stream(dev)
+        self.s_enc.wait_stream(cur)
+        self.s_cmp.wait_stream(cur)
+        enc, stride = self.enc, self.enc.stride
+        mode = _lib.COMPACT_FRAMED if self.framed else _lib.COMPACT_DENSE
+        with torch.cuda.device(dev):
+            for i, (a, b) in enumerate(zip(self.bounds, self.bounds[1:])):
+                self.model.encode_rows_into(sym, a, b, enc, self.s_enc.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(self.s_enc)
+                self.s_cmp.wait_event(ev)
+                rc = L.scl_streams_compact_at(
+                    enc.data.data_ptr() + a * stride, enc.bit_offset.data_ptr() + 8 * a, enc.nbits.data_ptr() + 4 * a, b - a,
+                    mode, self.dense.data_ptr(), self.dense.numel(), self.offsets.data_ptr() + 8 * a,
+                    (self.offsets.data_ptr() + 8 * a) if i else None,  # starts where the previous sub-batch ended
+                    self.scratch.data_ptr() + self.scr * i, self.s_cmp.cuda_stream)
+                _lib.check(rc, "scl_streams_compact_at")
+        cur.wait_stream(self.s_cmp)
+        cur.wait_stream(self.s_enc)
+        return self.dense, self.offsets

@@ -219,11 +219,13 @@ __global__ void __launch_bounds__(CP_THREADS) cp_scan_sums(u64 *__restrict__ til
 }
 
 // pass 3: add tile bases; entry n = total
+// (base: where the first record starts, a value in device memory -- scl_streams_compact_at; tile_sum[n_tiles + 1] holds it)
 __global__ void cp_add_base(u64 *__restrict__ off, u64 n, const u64 *__restrict__ tile_sum,
-                            const u64 *__restrict__ total) {
+                            const u64 *__restrict__ total, const u64 *__restrict__ base) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) off[idx] += tile_sum[idx / CP_TILE];
-    if (idx == n) off[n] = *total;
+    const u64 b = base ? *base : 0;
+    if (idx < n) off[idx] += tile_sum[idx / CP_TILE] + b;
+    if (idx == n) off[n] = *total + b;
 }
 
 // pass 4: one wavefront per stream copies (bit-shifts) it to its record.
@@ -328,33 +330,55 @@ __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const 
 
 extern "C" uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks) {
     u64 n_tiles = (n_chunks + CP_TILE - 1) / CP_TILE;
-    return scl_round_up((n_tiles + 2) * sizeof(u64), 256);
+    return scl_round_up((n_tiles + 3) * sizeof(u64), 256);  // tile sums, the total, the base of scl_streams_compact_at
 }
 
-extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
-                                   uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
-                                   uint64_t *d_out_byte_offset, void *d_scratch, void *stream) {
+// The same with the first record at byte *d_base of d_out, d_base in DEVICE memory (NULL: 0): the offsets written are
+// absolute (d_out_byte_offset[0] = *d_base, [n] = where the next record would start).  A batch can so be compacted in
+// sub-batches into ONE dense buffer without the host ever knowing the sizes: sub-batch i + 1 passes the address of
+// sub-batch i's last offset entry -- which may be the very address it writes its own first entry to (the value is read
+// into the scratch before anything is written).  What lets the compaction of one sub-batch run on a second stream while the
+// next one is still being encoded (backend/models.py encode_dense_pipelined).
+extern "C" int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                                      uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                                      uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch,
+                                      void *stream) {
     SCL_REQUIRE(mode == SCL_COMPACT_DENSE || mode == SCL_COMPACT_FRAMED, "compact: unknown mode %d", mode);
     SCL_REQUIRE(d_in && d_bit_offset && d_nbits && d_out && d_out_byte_offset && d_scratch,
                 "compact: null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    if (n_chunks == 0) {
-        SCL_HIP_TRY(hipMemsetAsync(d_out_byte_offset, 0, sizeof(u64), st));
-        return SCL_OK;
-    }
     const u64 n_tiles = (n_chunks + CP_TILE - 1) / CP_TILE;
     u64 *tile_sum = (u64 *)d_scratch;
     u64 *total = tile_sum + n_tiles;
+    u64 *base = nullptr;
+    if (d_base) {  // first, before any offset entry is written: d_base may alias d_out_byte_offset[0]
+        base = total + 1;
+        SCL_HIP_TRY(hipMemcpyAsync(base, d_base, sizeof(u64), hipMemcpyDeviceToDevice, st));
+    }
+    if (n_chunks == 0) {
+        if (base)
+            SCL_HIP_TRY(hipMemcpyAsync(d_out_byte_offset, base, sizeof(u64), hipMemcpyDeviceToDevice, st));
+        else
+            SCL_HIP_TRY(hipMemsetAsync(d_out_byte_offset, 0, sizeof(u64), st));
+        return SCL_OK;
+    }
     hipLaunchKernelGGL(cp_scan_tiles, dim3((u32)n_tiles), dim3(CP_THREADS), 0, st, d_nbits, n_chunks, mode,
                        d_out_byte_offset, tile_sum);
     hipLaunchKernelGGL(cp_scan_sums, dim3(1), dim3(CP_THREADS), 0, st, tile_sum, n_tiles, total);
     hipLaunchKernelGGL(cp_add_base, dim3((u32)((n_chunks + 1 + 255) / 256)), dim3(256), 0, st, d_out_byte_offset,
-                       n_chunks, tile_sum, total);
+                       n_chunks, tile_sum, total, base);
     const u64 waves_per_block = 256 / SCL_WAVE;
     hipLaunchKernelGGL(cp_copy, dim3((u32)((n_chunks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, st,
                        d_in, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
+}
+
+extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                                   uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                                   uint64_t *d_out_byte_offset, void *d_scratch, void *stream) {
+    return scl_streams_compact_at(d_in, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset,
+                                  nullptr, d_scratch, stream);
 }
 
 // ---- symbol histogram (row f3) ----------------------------------------------------------------------

@@ -251,3 +251,32 @@ def test_stream_driver_custom_writer_and_bounded_batches(tmp_path, monkeypatch):
         rANSDecoder(params).decode(r, ListDataStream([]))
     import inspect
     assert "assert " not in "".join(ln for ln in inspect.getsource(_stream_batch).splitlines(True) if ln.lstrip().startswith("assert"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coder", ["rans", "range", "tans"])
+@pytest.mark.parametrize("framed", [False, True])
+def test_dense_pipeline_equals_sequential_compaction(coder, framed):
+    """``DensePipeline`` (sub-batches on two streams, ``scl_streams_compact_at`` chaining the offsets on the device) writes,
+    byte for byte, what encode + ``scl_streams_compact`` of the whole batch write -- dense and in the reference's framed
+    file format (core/encoded_stream.py:150-175) -- for every split, incl. sub-batches of one chunk"""
+    from stanford_compression_library_amd import bench_data
+    from stanford_compression_library_amd.backend import models
+
+    backend_lib.require_device()
+    dev = torch.device("cuda:0")
+    freq = bench_data.t256_table()
+    model = {"rans": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32),
+             "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
+             "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[coder]()
+    n_chunks, chunk_len = 777, 1008
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=11, device=dev)
+    want, want_offs = models.compact(model.encode_batch(sym), framed=framed)
+    total = int(want_offs[-1])
+    for n_sub in (1, 2, 3, 7, n_chunks):
+        pipe = models.DensePipeline(model, n_chunks, chunk_len, dev, n_sub=n_sub, framed=framed)
+        for _ in range(2):  # a second run reuses the buffers
+            dense, offs = pipe.run(sym)
+            torch.cuda.synchronize()
+            assert torch.equal(offs, want_offs), f"n_sub={n_sub}: offsets differ"
+            assert torch.equal(dense[:total], want[:total]), f"n_sub={n_sub}: bytes differ"
