@@ -162,7 +162,7 @@ def csrc_sha(coder):
     d = os.path.join(ROOT, "stanford_compression_library_amd", "csrc")
     fam = {"rans": ("scl_rans",), "tans": ("scl_rans", "scl_tans"), "range": ("scl_range",), "aec": ("scl_aec",)}[coder]
     names = sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h")) and
-                   (n.startswith(fam) or n in ("scl_common.h", "scl_ans_fast_io.h", "scl_core.hip")))
+                   (n.startswith(fam) or n in ("scl_common.h", "scl_ans_fast_io.h")))
     h = hashlib.sha256()
     for n in names:
         h.update(n.encode() + b"\0" + open(os.path.join(d, n), "rb").read())

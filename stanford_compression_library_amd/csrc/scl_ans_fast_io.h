@@ -196,7 +196,10 @@ __device__ __forceinline__ u32 scl_quad_bcast(u32 v) {  // value of lane R of th
 template <int THREADS>
 struct AnsBackWriterL {
     static constexpr u32 FLUSH_MASK = 3;   // the encoder's flush points: every (FLUSH_MASK + 1) x 16 symbols
-    static constexpr u32 FLUSH_PHASE = 1;  // ... after block 1 (mod 4) of a line
+#ifndef RF_FLUSH_PHASE_L
+#define RF_FLUSH_PHASE_L 1
+#endif
+    static constexpr u32 FLUSH_PHASE = RF_FLUSH_PHASE_L;  // ... after block 1 (mod 4) of a line
     static constexpr u32 WG_PER_CU = 2;    // 64 KiB of rings + the 4 KiB table per 256 lanes
     static constexpr u32 LANE_BYTES = 256;                   // one 256-byte ring per lane, 256-byte aligned
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup

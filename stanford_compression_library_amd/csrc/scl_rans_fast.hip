@@ -172,10 +172,12 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
         const Entries4 cur = pre;
         pre.load(wv[d + 1], tab);
         asm volatile("" ::: "memory");  // keep the reads here: the compiler would sink them to their first use
-#if RF_WAITMERGE
+#if RF_WAITMERGE == 1
         // the four entries of this word were issued back to back a whole word ago: touching the LAST of them first makes the
         // compiler wait once (lgkmcnt(4): only the reads just issued may still be in flight) instead of once per symbol
         asm volatile("" : : "v"(cur.e[3].k_lo));
+#elif RF_WAITMERGE == 2  // experiment: two waits per word
+        asm volatile("" : : "v"(cur.e[1].k_lo));
 #endif
         if (CHECK_SYM) {
             const u32 w = wv[d];
