@@ -257,15 +257,9 @@ __global__ void __launch_bounds__(AF_THREADS)
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
 #define AD_OUT_BASE AF_TABLE_BYTES                 // [thread][64 bytes]
 #define AD_OUT_BYTES (AF_THREADS * 64)
-#define AD_LUT_BASE (AD_OUT_BASE + AD_OUT_BYTES)   // LUT[s][j] = (j >= s)
-#define AD_LDS_BYTES (AD_LUT_BASE + 512)
+#define AD_LDS_BYTES (AD_OUT_BASE + AD_OUT_BYTES)
 
 __device__ __forceinline__ void ad_setup_tables(char *lds, const AecFastDev &P, u32 tid) {
-    if (tid < 128) {
-        const u32 s = tid >> 3, r = tid & 7;  // register r holds elements 2r, 2r+1
-        const u32 v = ((2 * r >= s) ? 1u : 0u) | ((2 * r + 1 >= s) ? 0x10000u : 0u);
-        *reinterpret_cast<u32_lds *>(lds + AD_LUT_BASE + s * 32 + r * 4) = v;
-    }
     // inclusive from the exclusive initX: Y[j] = X[j + 1], Y[15] = total
     u32 y[8];
 #pragma unroll
@@ -329,35 +323,23 @@ __global__ void __launch_bounds__(AF_THREADS)
         const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
         u32 tgt = (u32)(num * xr);
         tgt = min(tgt, T - 1);
-        const u32 tp = tgt | (tgt << 16);
-        u32 acc0 = 0, acc1 = 0;
-        acc0 = af_pk_count_gt(acc0, tp, R.a.x);
-        acc1 = af_pk_count_gt(acc1, tp, R.a.y);
-        acc0 = af_pk_count_gt(acc0, tp, R.a.z);
-        acc1 = af_pk_count_gt(acc1, tp, R.a.w);
-        acc0 = af_pk_count_gt(acc0, tp, R.b.x);
-        acc1 = af_pk_count_gt(acc1, tp, R.b.y);
-        acc0 = af_pk_count_gt(acc0, tp, R.b.z);
-        acc1 = af_pk_count_gt(acc1, tp, R.b.w);
-        const u32 acc = af_pk_add(acc0, acc1);
-        // s = #{j : Y[j] <= target} = 16 - #{Y[j] > target}; Y[15] = T > target, so s <= 15, and entries past the alphabet
-        // hold T as well, so s <= K - 1
-        const u32 s = 16u + (u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16);
+        // s = #{j : Y[j] <= target}; Y[15] = T > target, so s <= 15, and entries past the alphabet hold T as well, so
+        // s <= K - 1
+        const u32 Y[8] = {R.a.x, R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w};
+        u32 msk[8];
+        const u32 s = af_pk_search16(Y, tgt, msk);
         const u32 rowbase = ctx * AF_CTX_BYTES + tid * 32;
-        // c = Y[s - 1], d = Y[s]: one aligned-to-2 pair of u16 reads; s = 0 reads the two bytes in front of the row and
-        // replaces them by 0
+        // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
+        // the row and replaces them by 0
         const u32 ea = rowbase + 2 * s;
         const u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea - 2);
         const u32 d = *reinterpret_cast<const u16_lds *>(lds + ea);
         const u32 c = s ? c_raw : 0u;
-        {  // update_model: Y[j] += 1 for j >= s
-            const uint4 ia = *reinterpret_cast<const uint4_lds *>(lds + AD_LUT_BASE + s * 32);
-            const uint4 ib = *reinterpret_cast<const uint4_lds *>(lds + AD_LUT_BASE + s * 32 + 16);
-            *reinterpret_cast<uint4_lds *>(lds + rowbase) =
-                make_uint4(af_pk_add(R.a.x, ia.x), af_pk_add(R.a.y, ia.y), af_pk_add(R.a.z, ia.z), af_pk_add(R.a.w, ia.w));
-            *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) =
-                make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
-        }
+        // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
+        *reinterpret_cast<uint4_lds *>(lds + rowbase) =
+            make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
+        *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) =
+            make_uint4(af_pk_sub(Y[4], msk[4]), af_pk_sub(Y[5], msk[5]), af_pk_sub(Y[6], msk[6]), af_pk_sub(Y[7], msk[7]));
         ctx = af_next_ctx<ORDER1>(P, ctx, s);
         // next symbol's row: issued now, needed only after the arithmetic below
         R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
@@ -394,9 +376,7 @@ __global__ void __launch_bounds__(AF_THREADS)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            const u32 bits = rd.get(kt);
-            const u32 keep = (state << k) & AF_HALF;
-            state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
+            state = af_state_shift_in(rd, state, k, kt);
             low = nlow;
             hm = nhm;
             used += kt;

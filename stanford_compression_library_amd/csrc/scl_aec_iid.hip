@@ -45,22 +45,6 @@ __device__ __forceinline__ AiRow ai_row_add(const AiRow &R, const uint4 &ia, con
     o.b = make_uint4(af_pk_add(R.b.x, ib.x), af_pk_add(R.b.y, ib.y), af_pk_add(R.b.z, ib.z), af_pk_add(R.b.w, ib.w));
     return o;
 }
-// number of the 16 packed u16 of R that are > t  (all values < 2^15), as a positive count
-__device__ __forceinline__ u32 ai_count_gt(const AiRow &R, u32 t) {
-    const u32 tp = t | (t << 16);
-    u32 a0 = 0, a1 = 0;
-    a0 = af_pk_count_gt(a0, tp, R.a.x);
-    a1 = af_pk_count_gt(a1, tp, R.a.y);
-    a0 = af_pk_count_gt(a0, tp, R.a.z);
-    a1 = af_pk_count_gt(a1, tp, R.a.w);
-    a0 = af_pk_count_gt(a0, tp, R.b.x);
-    a1 = af_pk_count_gt(a1, tp, R.b.y);
-    a0 = af_pk_count_gt(a0, tp, R.b.z);
-    a1 = af_pk_count_gt(a1, tp, R.b.w);
-    const u32 acc = af_pk_add(a0, a1);
-    return 0u - ((u32)((int32_t)(acc << 16) >> 16) + (u32)((int32_t)acc >> 16));
-}
-
 __device__ __forceinline__ void ai_setup_tables(char *lds, const AecIidDev &P, u32 tid) {
     if (tid < 128) {  // mask rows, register r of a row holds elements 2r and 2r+1
         const u32 s = tid >> 3, r = tid & 7;
@@ -259,30 +243,32 @@ __global__ void __launch_bounds__(AI_THREADS)
         const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
         u32 tgt = (u32)(num * xr);  // ((state - low + 1) * T - 1) // rng, see scl_aec.hip
         tgt = min(tgt, T - 1);
-        // block: largest b with XB[b] <= target  (XB[0] = 0 always counts)
-        const u32 b = min(15u - ai_count_gt(XB, tgt), last_block);
+        // block: largest b with XB[b] <= target  (XB[0] = 0 always counts).  Both searches hand back their compare masks:
+        // the rows are sorted, so "entry > target" is exactly the set update_model increments (af_pk_search16)
+        const u32 XBv[8] = {XB.a.x, XB.a.y, XB.a.z, XB.a.w, XB.b.x, XB.b.y, XB.b.z, XB.b.w};
+        u32 xbm[8], icm[8];
+        const u32 b = min(af_pk_search16(XBv, tgt, xbm) - 1u, last_block);
         const u32 rowaddr = AI_IC_BASE + b * AI_ROW_BYTES + tid * 32;
         const u32 xb = *reinterpret_cast<const u16_lds *>(lds + tid * 32 + 2 * b);
         AiRow IC;
         IC.a = *reinterpret_cast<const uint4_lds *>(lds + rowaddr);
         IC.b = *reinterpret_cast<const uint4_lds *>(lds + rowaddr + 16);
-        const uint4 gt_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32);
-        const uint4 gt_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GT_BASE + b * 32 + 16);
         // symbol inside the block: number of inclusive sums <= target - XB[b]
         const u32 t2 = tgt - xb;
-        u32 w = 16u - ai_count_gt(IC, t2);
+        const u32 ICv[8] = {IC.a.x, IC.a.y, IC.a.z, IC.a.w, IC.b.x, IC.b.y, IC.b.z, IC.b.w};
+        u32 w = af_pk_search16(ICv, t2, icm);
         w = min(w, min(15u, P.K - 1 - 16 * b));
         const u32 s = 16 * b + w;
         const u32 ic = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w);
         const u32 icm1 = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w - 2);
-        const uint4 ge_a = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32);
-        const uint4 ge_b = *reinterpret_cast<const uint4_lds *>(lds + AI_LUT_GE_BASE + w * 32 + 16);
         const u32 c = xb + (w ? icm1 : 0u), d = xb + ic;
         // update_model
-        const AiRow IC2 = ai_row_add(IC, ge_a, ge_b);
-        *reinterpret_cast<uint4_lds *>(lds + rowaddr) = IC2.a;
-        *reinterpret_cast<uint4_lds *>(lds + rowaddr + 16) = IC2.b;
-        XB = ai_row_add(XB, gt_a, gt_b);
+        *reinterpret_cast<uint4_lds *>(lds + rowaddr) =
+            make_uint4(af_pk_sub(ICv[0], icm[0]), af_pk_sub(ICv[1], icm[1]), af_pk_sub(ICv[2], icm[2]), af_pk_sub(ICv[3], icm[3]));
+        *reinterpret_cast<uint4_lds *>(lds + rowaddr + 16) =
+            make_uint4(af_pk_sub(ICv[4], icm[4]), af_pk_sub(ICv[5], icm[5]), af_pk_sub(ICv[6], icm[6]), af_pk_sub(ICv[7], icm[7]));
+        XB.a = make_uint4(af_pk_sub(XBv[0], xbm[0]), af_pk_sub(XBv[1], xbm[1]), af_pk_sub(XBv[2], xbm[2]), af_pk_sub(XBv[3], xbm[3]));
+        XB.b = make_uint4(af_pk_sub(XBv[4], xbm[4]), af_pk_sub(XBv[5], xbm[5]), af_pk_sub(XBv[6], xbm[6]), af_pk_sub(XBv[7], xbm[7]));
         *reinterpret_cast<uint4_lds *>(lds + tid * 32) = XB.a;
         *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
         af_shrink2(low, hm, c, d, xT);
@@ -319,9 +305,7 @@ __global__ void __launch_bounds__(AI_THREADS)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            const u32 bits = rd.get(kt);
-            const u32 keep = (state << k) & AF_HALF;
-            state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
+            state = af_state_shift_in(rd, state, k, kt);
             low = nlow;
             hm = nhm;
             used += kt;

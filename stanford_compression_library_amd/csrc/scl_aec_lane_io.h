@@ -28,6 +28,25 @@ __device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
     return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, acc) + d));
 }
 
+// decoder search over one row of 16 nondecreasing u16 (8 packed registers): m[r] = (e > t) ? 0xFFFF : 0 per half, and the
+// number of entries <= t.  The row is sorted, so e[j] > t  <=>  j >= s: the masks ARE update_model's increment
+// (Y[j] += 1 for j >= s is Y - m), no mask table to read; the count comes out of v_dot2c_i32_i16 without a combine step.
+__device__ __forceinline__ u32 af_pk_search16(const u32 (&e)[8], u32 t, u32 (&m)[8]) {
+    const s16x2 tp = __builtin_bit_cast(s16x2, t | (t << 16));
+    const s16x2 one = {1, 1};
+    int acc = 16;
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const s16x2 d = (tp - __builtin_bit_cast(s16x2, e[r])) >> (s16x2)(15);
+        m[r] = __builtin_bit_cast(u32, d);
+        acc = __builtin_amdgcn_sdot2(d, one, acc, false);
+    }
+    return (u32)acc;
+}
+__device__ __forceinline__ u32 af_pk_sub(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
+}
+
 // ---- forward bit writer: completed big-endian words go straight to the slot (4-byte stores; the stream is a
 // third of the input and L2 merges them -- a register FIFO costs ~50 phi copies per symbol, an LDS ring does not fit)
 // STAGED (round 4): completed words collect in 64 bytes of LDS per lane ([thread][64 bytes] at `lds_stage`) and leave as
@@ -103,13 +122,16 @@ typedef AfWriterT<false> AfWriter;
 
 // ---- forward bit reader: 4-byte loads, one word ahead; bits past the end of the stream read as 0 ---------------
 struct AfReader {
+    // Two 32-bit words of the stream in registers: the unread bits are the low `r` bits of `a` (0 <= r <= 31) followed by `b`,
+    // so the next 32 bits are one v_alignbit(a, b, r) -- no 64-bit window to shift (round 4; the window cost two 64-bit
+    // shifts, a counter and an "nb == 0" branch per symbol).
     const u32 *base;
     u64 nwords;  // readable 32-bit words
     u64 wi;      // index of the word held in `ahead`
-    u32 ahead;   // raw (memory-order) word wi
-    u64 win;     // bit window, left-aligned
-    u32 nwin;    // valid bits in win (>= 32 between calls)
-    i64 rem;     // stream bits not yet moved into the window (may go negative)
+    u32 ahead;   // raw (memory-order) word wi, loaded one refill early
+    u32 a, b;
+    int r;
+    i64 rem;     // stream bits not yet moved into a/b (may go negative)
 
     // index clamped instead of a conditional load (which would have to be waited for at once); words past the
     // end of the stream are zeroed by `rem` below whatever was loaded
@@ -128,27 +150,43 @@ struct AfReader {
         ahead = load(wi);
         const u32 skipb = (u32)bit_off & 31u;
         rem = (i64)nbits + skipb;
-        const u64 hiw = next_word();
-        const u64 low_ = next_word();
-        win = (hiw << 32) | low_;
-        nwin = 64;
-        if (skipb) {  // drop the bits in front of the stream (>= 33 valid bits remain)
-            win <<= skipb;
-            nwin -= skipb;
+        a = 0;
+        b = next_word();
+        r = 0;
+        consume(skipb);  // drop the bits in front of the stream
+    }
+    __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(a, b, (u32)r); }  // the next 32 bits
+    __device__ __forceinline__ void consume(u32 nb) {  // nb <= 31
+        r -= (int)nb;
+        if (r < 0) {
+            a = b;
+            b = next_word();
+            r += 32;
         }
     }
-    __device__ __forceinline__ u32 get(u32 nb) {  // nb <= 32
-        if (nb == 0) return 0;
-        const u32 v = (u32)(win >> (64 - nb));
-        win <<= nb;
-        nwin -= nb;
-        if (nwin < 32) {
-            win |= (u64)next_word() << (32 - nwin);
-            nwin += 32;
+    __device__ __forceinline__ u32 get(u32 nb) {  // nb <= 32; headers, the first state and the literal loops
+        const u32 l = look();
+        if (nb == 32) {
+            a = b;
+            b = next_word();
+            return l;
         }
-        return v;
+        consume(nb);
+        return nb ? l >> (32 - nb) : 0u;
     }
 };
+
+// the closed-form renormalisation's state update: kt = k + m <= 31 bits come in from the stream, the bit k steps below the
+// top is kept on top (the E3 steps), arithmetic_coding.py:245-275.  {state, look} << kt is one 64-bit shift and kt = 0 needs
+// no special case.
+__device__ __forceinline__ u32 af_state_shift_in(AfReader &rd, u32 state, u32 k, u32 kt) {
+    u32 l = rd.look();
+    asm volatile("" : "+v"(l));  // taken before the refill branch, so that a/b/r are updated in place there
+    const u64 both = (((u64)state << 32) | l) << kt;
+    const u32 keep = (state << k) & 0x80000000u;
+    rd.consume(kt);
+    return ((u32)(both >> 32) & 0x7FFFFFFFu) | keep;
+}
 
 // ---- decoded symbols: four to a word, sixteen words to a 64-byte sector staged in LDS ([thread][64 bytes]), stored as four
 // back-to-back 16-byte stores.  One 4-byte store per four symbols -- what these kernels did until round 4 -- is not merged by

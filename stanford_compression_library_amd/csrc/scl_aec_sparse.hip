@@ -462,9 +462,7 @@ __global__ void __launch_bounds__(AP_THREADS)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            const u32 bits = rd.get(kt);
-            const u32 keep = (state << k) & AF_HALF;
-            state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
+            state = af_state_shift_in(rd, state, k, kt);
             low = nlow;
             hm = nhm;
             used += kt;
