@@ -713,7 +713,7 @@ extern "C" int scl_aec_decode_batch(const scl_aec_model *m, const uint8_t *d_in,
     SCL_REQUIRE(((uintptr_t)d_in & 3) == 0, "aec_decode_batch: d_in must be 4-byte aligned");
     if (n_chunks == 0) return SCL_OK;
     hipStream_t st = (hipStream_t)stream;
-    const bool tuned = !scl_force_generic();
+    const bool tuned = !scl_force_generic() && in_size_bytes >= 4;  // the tuned readers load whole 32-bit words
     RowRelay relay;  // output rows the tuned kernels cannot store to go through aligned scratch and are copied back
     if (tuned && (aec_fast_ok(m, out_cap) || aec_iid_ok(m, out_cap) || aec_static_ok(m) || aec_wide_ok(m, out_cap)) &&
         ((uintptr_t)d_in & 15) == 0)

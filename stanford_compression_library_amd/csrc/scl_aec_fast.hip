@@ -314,10 +314,11 @@ __global__ void __launch_bounds__(AF_THREADS)
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
     AfRow R = af_row_load(lds, tid * 32);
-    for (u32 i = 0;; ++i) {
-        // ---- decode_step_core, :177-201 ----
+    // One symbol: decode_step_core (:177-201), update_model, symbol out.  The loop runs it for all but the last symbol of the
+    // chunk, the last one follows the loop without a renormalisation (the reference breaks before it, :242-243): a single
+    // exit test per iteration.
+    auto step = [&](u32 i) {
         const u32 T = R.b.w >> 16;  // Y[15]
-        const double xT = af_recip((double)T);  // independent of the search below
         const double xr = af_recip((double)(hm - low) + 1.0);
         // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip), clamped for corrupt streams
         const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
@@ -332,9 +333,8 @@ __global__ void __launch_bounds__(AF_THREADS)
         // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
         // the row and replaces them by 0
         const u32 ea = rowbase + 2 * s;
-        const u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea - 2);
-        const u32 d = *reinterpret_cast<const u16_lds *>(lds + ea);
-        const u32 c = s ? c_raw : 0u;
+        u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea - 2);
+        u32 d = *reinterpret_cast<const u16_lds *>(lds + ea);
         // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
         *reinterpret_cast<uint4_lds *>(lds + rowbase) =
             make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
@@ -343,12 +343,24 @@ __global__ void __launch_bounds__(AF_THREADS)
         ctx = af_next_ctx<ORDER1>(P, ctx, s);
         // next symbol's row: issued now, needed only after the arithmetic below
         R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
+        // (the empty asm keeps the two values 32 bits wide: narrowed to 16-bit operations they each cost a v_and 0xffff)
+        // and the two around 1/T place its seven instructions after the search and before that wait: they run while the two
+        // reads are in flight)
+        u32 T2 = T;
+        asm volatile("" : "+v"(T2) : "v"(s));
+        double xT = af_recip((double)T2);
+        asm volatile("" : "+v"(xT));
+        asm volatile("" : "+v"(c_raw), "+v"(d));
+        const u32 c = c_raw & ~msk[0];  // s = 0 <=> Y[0] > target <=> the low half of msk[0] is all ones
         af_shrink2(low, hm, c, d, xT);
         so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
-        if (i + 1 == n) break;  // before the renormalisation, :242-243
+    };
+    u32 i = 0;
+    for (; i + 1 < n; ++i) {
+        step(i);
         // ---- renormalisation, :245-275 ----
         u32 k, m, nlow, nhm;
-        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
+        const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -382,6 +394,7 @@ __global__ void __launch_bounds__(AF_THREADS)
             used += kt;
         }
     }
+    step(i);  // i = n - 1
     so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(AI_THREADS)
         if (i + 1 == n) break;  // before the renormalisation, :242-243
         // ---- renormalisation, :245-275 ----
         u32 k, m, nlow, nhm;
-        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
+        const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {

@@ -125,31 +125,39 @@ struct AfReader {
     // Two 32-bit words of the stream in registers: the unread bits are the low `r` bits of `a` (0 <= r <= 31) followed by `b`,
     // so the next 32 bits are one v_alignbit(a, b, r) -- no 64-bit window to shift (round 4; the window cost two 64-bit
     // shifts, a counter and an "nb == 0" branch per symbol).
-    const u32 *base;
-    u64 nwords;  // readable 32-bit words
-    u64 wi;      // index of the word held in `ahead`
-    u32 ahead;   // raw (memory-order) word wi, loaded one refill early
+    // A refill is taken by SOME lane of the wave at nearly every symbol (the lanes' word boundaries are out of phase), so
+    // its instruction count is paid per symbol: one 32-bit counter does both the bounds check and the zero fill.
+    const u32 *ptr;  // address of the word held in `ahead`
+    u32 ahead;       // raw (memory-order) word, loaded one refill early
     u32 a, b;
     int r;
-    i64 rem;     // stream bits not yet moved into a/b (may go negative)
+    u32 left;        // words of the stream not yet moved into a/b, the partial last one included, clipped to the buffer
+    u32 tail;        // mask of the stream's bits in its last word (all ones if it ends on a word boundary); 0 once used
 
-    // index clamped instead of a conditional load (which would have to be waited for at once); words past the
-    // end of the stream are zeroed by `rem` below whatever was loaded
-    __device__ __forceinline__ u32 load(u64 j) const { return base[min(j, nwords - 1)]; }
+    // The word in `ahead` becomes part of the window; bits past the end of the stream read as zero (the arithmetic
+    // decoder looks PRECISION bits ahead, arithmetic_coding.py:222-229), and no load goes past the stream's last word.
     __device__ __forceinline__ u32 next_word() {
-        u32 v = __builtin_bswap32(ahead);
-        ahead = load(++wi);
-        if (rem < 32) v = (rem <= 0) ? 0u : (v & ~(0xFFFFFFFFu >> rem));
-        rem -= 32;
+        const bool more = left > 1u;
+        const u32 v = __builtin_bswap32(ahead) & (more ? 0xFFFFFFFFu : tail);
+        tail = more ? tail : 0u;
+        left = left ? left - 1u : 0u;
+        ptr = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(ptr) + (more ? 4 : 0));
+        ahead = *ptr;
         return v;
     }
     __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 nbits) {
-        base = reinterpret_cast<const u32 *>(in);
-        nwords = in_size_bytes >> 2;
-        wi = bit_off >> 5;
-        ahead = load(wi);
+        const u64 nwords = in_size_bytes >> 2;  // readable 32-bit words
+        const u64 wi = min(bit_off >> 5, nwords - 1);
         const u32 skipb = (u32)bit_off & 31u;
-        rem = (i64)nbits + skipb;
+        const u64 sbits = (u64)nbits + skipb;                       // from the start of word wi
+        const u64 swords = (sbits + 31) >> 5;
+        const u64 avail = (bit_off >> 5) < nwords ? nwords - wi : 0;  // a stream that starts past the buffer reads as zeros
+        left = (u32)min(min(swords, avail), (u64)0xFFFFFFFFu);
+        const u32 tb = (u32)sbits & 31u;
+        tail = (left < swords) ? 0xFFFFFFFFu : (tb ? ~(0xFFFFFFFFu >> tb) : 0xFFFFFFFFu);
+        if (left == 0) tail = 0;
+        ptr = reinterpret_cast<const u32 *>(in) + wi;
+        ahead = *ptr;
         a = 0;
         b = next_word();
         r = 0;

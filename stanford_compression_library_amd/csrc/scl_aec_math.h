@@ -79,3 +79,16 @@ __device__ __forceinline__ bool af_renorm2(u32 low, u32 hm, u32 &k, u32 &m, u32 
     nhm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
     return (nlow == 0 && low != 0) || (nhm == 0xFFFFFFFFu && hm != 0xFFFFFFFFu);
 }
+
+// The decoders' variant: the corner test without the "low != 0" / "hm != 2^32 - 1" exclusions -- two compares fewer per
+// symbol.  It sends a few more symbols through the literal loops (exact for every interval): those coded while low is still
+// 0 or high still 2^32, i.e. the first symbols of a chunk.
+__device__ __forceinline__ bool af_renorm2_dec(u32 low, u32 hm, u32 &k, u32 &m, u32 &nlow, u32 &nhm) {
+    k = (u32)__builtin_clz(low ^ hm);
+    const u32 z = ((low & ~hm) << k) << 1;
+    m = (u32)__builtin_clz(~z);
+    const u32 kt = k + m;  // <= 31
+    nlow = (low << kt) & 0x7FFFFFFFu;
+    nhm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+    return nlow == 0 || nhm == 0xFFFFFFFFu;
+}
