@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(AF_THREADS)
 // Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
 // back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
-#define AD_OUT_BASE AF_TABLE_BYTES                 // [thread][64 bytes]
+#define AD_ROW_BASE 16                             // rows start 16 bytes in: the address "two bytes before a row" is never negative
+#define AD_OUT_BASE (AD_ROW_BASE + AF_TABLE_BYTES)  // [thread][64 bytes]
 #define AD_OUT_BYTES (AF_THREADS * 64)
 #define AD_LDS_BYTES (AD_OUT_BASE + AD_OUT_BYTES)
 
@@ -271,8 +272,8 @@ __device__ __forceinline__ void ad_setup_tables(char *lds, const AecFastDev &P, 
     const uint4 a = make_uint4(y[0], y[1], y[2], y[3]);
     const uint4 b = make_uint4(y[4], y[5], y[6], y[7]);
     for (u32 c = 0; c < P.nctx; ++c) {
-        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32) = a;
-        *reinterpret_cast<uint4_lds *>(lds + c * AF_CTX_BYTES + tid * 32 + 16) = b;
+        *reinterpret_cast<uint4_lds *>(lds + AD_ROW_BASE + c * AF_CTX_BYTES + tid * 32) = a;
+        *reinterpret_cast<uint4_lds *>(lds + AD_ROW_BASE + c * AF_CTX_BYTES + tid * 32 + 16) = b;
     }
     __syncthreads();
 }
@@ -313,36 +314,37 @@ __global__ void __launch_bounds__(AF_THREADS)
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
-    AfRow R = af_row_load(lds, tid * 32);
+    AfRow R = af_row_load(lds, AD_ROW_BASE + tid * 32);
+    const u32 lane_m2 = AD_ROW_BASE + tid * 32 - 2;  // two bytes before the lane's row of context 0
     // One symbol: decode_step_core (:177-201), update_model, symbol out.  The loop runs it for all but the last symbol of the
     // chunk, the last one follows the loop without a renormalisation (the reference breaks before it, :242-243): a single
     // exit test per iteration.
     auto step = [&](u32 i) {
         const u32 T = R.b.w >> 16;  // Y[15]
         const double xr = af_recip((double)(hm - low) + 1.0);
-        // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip), clamped for corrupt streams
+        // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip).  low <= state <= hm holds for ANY input bits (the
+        // symbol chosen is the one whose interval holds the state), so target <= T - 1; the guard is on s below.
         const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
-        u32 tgt = (u32)(num * xr);
-        tgt = min(tgt, T - 1);
+        const u32 tgt = (u32)(num * xr);
         // s = #{j : Y[j] <= target}; Y[15] = T > target, so s <= 15, and entries past the alphabet hold T as well, so
         // s <= K - 1
         const u32 Y[8] = {R.a.x, R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w};
         u32 msk[8];
-        const u32 s = af_pk_search16(Y, tgt, msk);
-        const u32 rowbase = ctx * AF_CTX_BYTES + tid * 32;
+        const u32 s = min(af_pk_search16(Y, tgt, msk), P.K - 1);
         // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
-        // the row and replaces them by 0
-        const u32 ea = rowbase + 2 * s;
-        u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea - 2);
-        u32 d = *reinterpret_cast<const u16_lds *>(lds + ea);
+        // the row, masked away below.  All addresses of the step hang off "row - 2": one add fewer than with "row" and "- 2".
+        const u32 row_m2 = ctx * AF_CTX_BYTES + lane_m2;
+        const u32 ea_m2 = row_m2 + 2 * s;
+        u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea_m2);
+        u32 d = *reinterpret_cast<const u16_lds *>(lds + ea_m2 + 2);
         // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
-        *reinterpret_cast<uint4_lds *>(lds + rowbase) =
+        *reinterpret_cast<uint4_lds *>(lds + row_m2 + 2) =
             make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
-        *reinterpret_cast<uint4_lds *>(lds + rowbase + 16) =
+        *reinterpret_cast<uint4_lds *>(lds + row_m2 + 18) =
             make_uint4(af_pk_sub(Y[4], msk[4]), af_pk_sub(Y[5], msk[5]), af_pk_sub(Y[6], msk[6]), af_pk_sub(Y[7], msk[7]));
         ctx = af_next_ctx<ORDER1>(P, ctx, s);
         // next symbol's row: issued now, needed only after the arithmetic below
-        R = af_row_load(lds, ctx * AF_CTX_BYTES + tid * 32);
+        R = af_row_load(lds, ctx * AF_CTX_BYTES + lane_m2 + 2);
         // (the empty asm keeps the two values 32 bits wide: narrowed to 16-bit operations they each cost a v_and 0xffff)
         // and the two around 1/T place its seven instructions after the search and before that wait: they run while the two
         // reads are in flight)

@@ -235,33 +235,41 @@ __global__ void __launch_bounds__(AI_THREADS)
     AiRow XB;
     XB.a = *reinterpret_cast<const uint4_lds *>(lds + tid * 32);
     XB.b = *reinterpret_cast<const uint4_lds *>(lds + tid * 32 + 16);
-    const u32 last_block = (P.K - 1) >> 4;
-    for (u32 i = 0;; ++i) {
-        // ---- decode_step_core, :177-201 ----
-        const double xT = af_recip((double)T);
+    // One symbol: decode_step_core (:177-201), update_model, symbol out; the last symbol of the chunk follows the loop without
+    // a renormalisation (the reference breaks before it, :242-243), so the loop has a single exit test.
+    // low <= state <= hm holds for ANY input bits (the symbol chosen is the one whose interval holds the state), so
+    // target <= T - 1, and with it b <= last block (XB of the blocks past the alphabet is T) and w <= the last symbol of the
+    // block (its sums stay at the block total past the alphabet): the searches need no clamps.  b <= 15 structurally
+    // (XB[0] = 0 <= target), which is what the addresses need; the guard on s is for the symbol written.
+    auto step = [&](u32 i) {
         const double xr = af_recip((double)(hm - low) + 1.0);
         const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
-        u32 tgt = (u32)(num * xr);  // ((state - low + 1) * T - 1) // rng, see scl_aec.hip
-        tgt = min(tgt, T - 1);
+        const u32 tgt = (u32)(num * xr);  // ((state - low + 1) * T - 1) // rng, see scl_aec.hip
         // block: largest b with XB[b] <= target  (XB[0] = 0 always counts).  Both searches hand back their compare masks:
         // the rows are sorted, so "entry > target" is exactly the set update_model increments (af_pk_search16)
         const u32 XBv[8] = {XB.a.x, XB.a.y, XB.a.z, XB.a.w, XB.b.x, XB.b.y, XB.b.z, XB.b.w};
         u32 xbm[8], icm[8];
-        const u32 b = min(af_pk_search16(XBv, tgt, xbm) - 1u, last_block);
+        const u32 b = (af_pk_search16(XBv, tgt, xbm) - 1u) & 15u;
         const u32 rowaddr = AI_IC_BASE + b * AI_ROW_BYTES + tid * 32;
-        const u32 xb = *reinterpret_cast<const u16_lds *>(lds + tid * 32 + 2 * b);
+        u32 xb = *reinterpret_cast<const u16_lds *>(lds + tid * 32 + 2 * b);
         AiRow IC;
         IC.a = *reinterpret_cast<const uint4_lds *>(lds + rowaddr);
         IC.b = *reinterpret_cast<const uint4_lds *>(lds + rowaddr + 16);
+        // 1/T: its seven instructions go here, while the row is in flight (the empty asm statements pin it between the block
+        // search and the first use of the row; they also keep the 16-bit reads 32 bits wide -- narrowed to 16-bit operations
+        // each costs a v_and 0xffff)
+        u32 T2 = T;
+        asm volatile("" : "+v"(T2) : "v"(b));
+        double xT = af_recip((double)T2);
+        asm volatile("" : "+v"(xT));
+        asm volatile("" : "+v"(xb));
         // symbol inside the block: number of inclusive sums <= target - XB[b]
         const u32 t2 = tgt - xb;
         const u32 ICv[8] = {IC.a.x, IC.a.y, IC.a.z, IC.a.w, IC.b.x, IC.b.y, IC.b.z, IC.b.w};
-        u32 w = af_pk_search16(ICv, t2, icm);
-        w = min(w, min(15u, P.K - 1 - 16 * b));
-        const u32 s = 16 * b + w;
-        const u32 ic = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w);
-        const u32 icm1 = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w - 2);
-        const u32 c = xb + (w ? icm1 : 0u), d = xb + ic;
+        const u32 w = af_pk_search16(ICv, t2, icm);
+        const u32 s = min(16 * b + w, P.K - 1);
+        u32 ic = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w);
+        u32 icm1 = *reinterpret_cast<const u16_lds *>(lds + rowaddr + 2 * w - 2);
         // update_model
         *reinterpret_cast<uint4_lds *>(lds + rowaddr) =
             make_uint4(af_pk_sub(ICv[0], icm[0]), af_pk_sub(ICv[1], icm[1]), af_pk_sub(ICv[2], icm[2]), af_pk_sub(ICv[3], icm[3]));
@@ -271,10 +279,16 @@ __global__ void __launch_bounds__(AI_THREADS)
         XB.b = make_uint4(af_pk_sub(XBv[4], xbm[4]), af_pk_sub(XBv[5], xbm[5]), af_pk_sub(XBv[6], xbm[6]), af_pk_sub(XBv[7], xbm[7]));
         *reinterpret_cast<uint4_lds *>(lds + tid * 32) = XB.a;
         *reinterpret_cast<uint4_lds *>(lds + tid * 32 + 16) = XB.b;
+        asm volatile("" : "+v"(ic), "+v"(icm1));
+        // w = 0 <=> IC[0] > target - XB[b] <=> the low half of icm[0] is all ones
+        const u32 c = xb + (icm1 & ~icm[0]), d = xb + ic;
         af_shrink2(low, hm, c, d, xT);
         T += 1;
         so.put(s, i);  // symbol out: whole 64-byte sectors (AfSymOut)
-        if (i + 1 == n) break;  // before the renormalisation, :242-243
+    };
+    u32 i = 0;
+    for (; i + 1 < n; ++i) {
+        step(i);
         // ---- renormalisation, :245-275 ----
         u32 k, m, nlow, nhm;
         const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
@@ -311,6 +325,7 @@ __global__ void __launch_bounds__(AI_THREADS)
             used += kt;
         }
     }
+    step(i);  // i = n - 1
     so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;

@@ -32,7 +32,7 @@ __device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
 // number of entries <= t.  The row is sorted, so e[j] > t  <=>  j >= s: the masks ARE update_model's increment
 // (Y[j] += 1 for j >= s is Y - m), no mask table to read; the count comes out of v_dot2c_i32_i16 without a combine step.
 __device__ __forceinline__ u32 af_pk_search16(const u32 (&e)[8], u32 t, u32 (&m)[8]) {
-    const s16x2 tp = __builtin_bit_cast(s16x2, t | (t << 16));
+    const s16x2 tp = {(short)t, (short)t};  // a splat: the compare reads the low half twice (op_sel), no v_lshl_or
     const s16x2 one = {1, 1};
     int acc = 16;
 #pragma unroll

@@ -89,6 +89,6 @@ __device__ __forceinline__ bool af_renorm2_dec(u32 low, u32 hm, u32 &k, u32 &m, 
     m = (u32)__builtin_clz(~z);
     const u32 kt = k + m;  // <= 31
     nlow = (low << kt) & 0x7FFFFFFFu;
-    nhm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
+    nhm = ~(~hm << kt) | AF_HALF;  // (hm << kt) | ones(kt) | HALF
     return nlow == 0 || nhm == 0xFFFFFFFFu;
 }
