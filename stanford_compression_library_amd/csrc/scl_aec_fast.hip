@@ -255,6 +255,9 @@ __global__ void __launch_bounds__(AF_THREADS)
 // Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
 // back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
+#ifndef AD_XT_PLACE
+#define AD_XT_PLACE 1  // 1: 1/T between the search and the wait for c, d; 0: wherever the compiler puts it (the top)
+#endif
 #define AD_ROW_BASE 16                             // rows start 16 bytes in: the address "two bytes before a row" is never negative
 #define AD_OUT_BASE (AD_ROW_BASE + AF_TABLE_BYTES)  // [thread][64 bytes]
 #define AD_OUT_BYTES (AF_THREADS * 64)
@@ -316,15 +319,19 @@ __global__ void __launch_bounds__(AF_THREADS)
     u32 ctx = 0;
     AfRow R = af_row_load(lds, AD_ROW_BASE + tid * 32);
     const u32 lane_m2 = AD_ROW_BASE + tid * 32 - 2;  // two bytes before the lane's row of context 0
+    u32 row_m2 = lane_m2;                            // the same for the current context: carried from symbol to symbol
     // One symbol: decode_step_core (:177-201), update_model, symbol out.  The loop runs it for all but the last symbol of the
     // chunk, the last one follows the loop without a renormalisation (the reference breaks before it, :242-243): a single
     // exit test per iteration.
     auto step = [&](u32 i) {
-        const u32 T = R.b.w >> 16;  // Y[15]
+        // T = Y[15] < 2^15, as float (one SDWA conversion out of the packed pair) and as double (from the float): both exact
+        float Tf;
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(Tf) : "v"(R.b.w));
+        const double Td = (double)Tf;
         const double xr = af_recip((double)(hm - low) + 1.0);
         // target = ((state - low + 1) * T - 1) // rng  (see scl_aec.hip).  low <= state <= hm holds for ANY input bits (the
         // symbol chosen is the one whose interval holds the state), so target <= T - 1; the guard is on s below.
-        const double num = __builtin_fma((double)(state - low) + 1.0, (double)T, -0.5);
+        const double num = __builtin_fma((double)(state - low) + 1.0, Td, -0.5);
         const u32 tgt = (u32)(num * xr);
         // s = #{j : Y[j] <= target}; Y[15] = T > target, so s <= 15, and entries past the alphabet hold T as well, so
         // s <= K - 1
@@ -333,10 +340,11 @@ __global__ void __launch_bounds__(AF_THREADS)
         const u32 s = min(af_pk_search16(Y, tgt, msk), P.K - 1);
         // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
         // the row, masked away below.  All addresses of the step hang off "row - 2": one add fewer than with "row" and "- 2".
-        const u32 row_m2 = ctx * AF_CTX_BYTES + lane_m2;
         const u32 ea_m2 = row_m2 + 2 * s;
-        u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea_m2);
-        u32 d = *reinterpret_cast<const u16_lds *>(lds + ea_m2 + 2);
+        // (one 4-byte read at a 2-byte-aligned address: LDS accesses need no alignment on gfx950 under amdhsa -- the compiler
+        // merges two adjacent 2-byte reads into exactly this on its own)
+        u32 cd;
+        __builtin_memcpy(&cd, lds + ea_m2, 4);
         // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
         *reinterpret_cast<uint4_lds *>(lds + row_m2 + 2) =
             make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
@@ -344,17 +352,22 @@ __global__ void __launch_bounds__(AF_THREADS)
             make_uint4(af_pk_sub(Y[4], msk[4]), af_pk_sub(Y[5], msk[5]), af_pk_sub(Y[6], msk[6]), af_pk_sub(Y[7], msk[7]));
         ctx = af_next_ctx<ORDER1>(P, ctx, s);
         // next symbol's row: issued now, needed only after the arithmetic below
-        R = af_row_load(lds, ctx * AF_CTX_BYTES + lane_m2 + 2);
-        // (the empty asm keeps the two values 32 bits wide: narrowed to 16-bit operations they each cost a v_and 0xffff)
-        // and the two around 1/T place its seven instructions after the search and before that wait: they run while the two
-        // reads are in flight)
-        u32 T2 = T;
+        asm("v_lshl_add_u32 %0, %1, 13, %2" : "=v"(row_m2) : "v"(ctx), "v"(lane_m2));  // ctx * AF_CTX_BYTES + lane_m2, one op
+        R = af_row_load(lds, row_m2 + 2);
+        // (the empty asm statements around 1/T place its seven instructions after the search and before the wait for c, d)
+        float T2 = Tf;
+#if AD_XT_PLACE == 1
         asm volatile("" : "+v"(T2) : "v"(s));
-        double xT = af_recip((double)T2);
+#endif
+        double xT = af_recip_fd(T2, Td);
         asm volatile("" : "+v"(xT));
-        asm volatile("" : "+v"(c_raw), "+v"(d));
-        const u32 c = c_raw & ~msk[0];  // s = 0 <=> Y[0] > target <=> the low half of msk[0] is all ones
-        af_shrink2(low, hm, c, d, xT);
+        asm volatile("" : "+v"(cd));
+        // c = low half, 0 for s = 0 (<=> Y[0] > target <=> the low half of msk[0] is all ones); d = high half, converted
+        // straight out of the pair (d < 2^15: exact as float)
+        const u32 c = cd & 0xFFFFu & ~msk[0];
+        float df;
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(df) : "v"(cd));
+        af_shrink2_d(low, hm, (double)c, (double)df, xT);
         so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
     };
     u32 i = 0;

@@ -34,12 +34,15 @@ __device__ __forceinline__ u32 af_pk_count_gt(u32 acc, u32 t, u32 e) {
 __device__ __forceinline__ u32 af_pk_search16(const u32 (&e)[8], u32 t, u32 (&m)[8]) {
     const s16x2 tp = {(short)t, (short)t};  // a splat: the compare reads the low half twice (op_sel), no v_lshl_or
     const s16x2 one = {1, 1};
-    int acc = 16;
+    int acc;
 #pragma unroll
     for (u32 r = 0; r < 8; ++r) {
         const s16x2 d = (tp - __builtin_bit_cast(s16x2, e[r])) >> (s16x2)(15);
         m[r] = __builtin_bit_cast(u32, d);
-        acc = __builtin_amdgcn_sdot2(d, one, acc, false);
+        if (r == 0)  // the three-address form with the constant 16 as accumulator: no v_mov to start the chain
+            asm("v_dot2_i32_i16 %0, %1, %2, 16" : "=v"(acc) : "v"(d), "s"(0x10001));
+        else
+            acc = __builtin_amdgcn_sdot2(d, one, acc, false);
     }
     return (u32)acc;
 }

@@ -18,6 +18,17 @@ __device__ __forceinline__ double af_recip(double v) {
     return x;
 }
 
+// the same for a small integer given as float AND as double (v < 2^24, both exact): the caller gets the float with one
+// SDWA conversion out of a packed field and the double from the float
+__device__ __forceinline__ double af_recip_fd(float vf, double v) {
+    double x = (double)__builtin_amdgcn_rcpf(vf);
+    double e = __builtin_fma(-v, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-v, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    return x;
+}
+
 // shrink_range (:58-78) on (low, hm = high - 1); c, d = c + f, T from the model, x = 1/T
 __device__ __forceinline__ void af_shrink(u32 &low, u32 &hm, u32 c, u32 d, u32 T, double x) {
     const double rd = (double)(hm - low) + 1.0;
@@ -48,6 +59,15 @@ __device__ __forceinline__ void af_shrink2(u32 &low, u32 &hm, u32 c, u32 d, doub
     const double rd = (double)(hm - low) + 1.0;
     const u32 q1 = (u32)(__builtin_fma(rd, (double)c, 0.5) * x);
     const u32 q2m1 = (u32)__builtin_fma(__builtin_fma(rd, (double)d, 0.5), x, -1.0);
+    hm = low + q2m1;
+    low = low + q1;
+}
+
+// the same with c and d already converted
+__device__ __forceinline__ void af_shrink2_d(u32 &low, u32 &hm, double c, double d, double x) {
+    const double rd = (double)(hm - low) + 1.0;
+    const u32 q1 = (u32)(__builtin_fma(rd, c, 0.5) * x);
+    const u32 q2m1 = (u32)__builtin_fma(__builtin_fma(rd, d, 0.5), x, -1.0);
     hm = low + q2m1;
     low = low + q1;
 }
