@@ -31,6 +31,7 @@
 //    straight to the slot (4-byte stores, L2 merges them); symbols arrive four per 32-bit load, one word ahead,
 //    the load unconditional so that it is not waited for at once.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "scl_aec_internal.h"
 #include "scl_aec_math.h"
@@ -370,10 +371,9 @@ __global__ void __launch_bounds__(AF_THREADS)
         af_shrink2_d(low, hm, (double)c, (double)df, xT);
         so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
     };
-    u32 i = 0;
-    for (; i + 1 < n; ++i) {
-        step(i);
-        // ---- renormalisation, :245-275 ----
+    // ---- renormalisation, :245-275; UNCHECKED selects the reader's refill (AfReader::next_word) ----
+    auto renorm = [&](auto unchecked) {
+        constexpr bool UC = decltype(unchecked)::value;
         u32 k, m, nlow, nhm;
         const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
@@ -388,14 +388,14 @@ __global__ void __launch_bounds__(AF_THREADS)
                     hi = (hi - AF_HALF) << 1;
                     stt = (stt - AF_HALF) << 1;
                 }
-                stt += rd.get(1);
+                stt += rd.get<UC>(1);
                 used++;
             }
             while (lo > AF_QTR && hi < 3ull * AF_QTR) {
                 lo = (lo - AF_QTR) << 1;
                 hi = (hi - AF_QTR) << 1;
                 stt = (stt - AF_QTR) << 1;
-                stt += rd.get(1);
+                stt += rd.get<UC>(1);
                 used++;
             }
             low = (u32)lo;
@@ -403,13 +403,37 @@ __global__ void __launch_bounds__(AF_THREADS)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            state = af_state_shift_in(rd, state, k, kt);
+            state = af_state_shift_in<UC>(rd, state, k, kt);
             low = nlow;
             hm = nhm;
             used += kt;
         }
+    };
+    // The symbol index i is the same for every lane still at work (they start together and only drop out), so it lives in a
+    // scalar register.  Stretches: as many symbols as EVERY working lane can decode without reaching the last word of its
+    // stream (and has left to decode) run with the unchecked refill and a scalar trip count; the last symbols of the chunks
+    // -- and everything, in a wave that holds a very short stream -- run in the checked loop below.
+    u32 i = 0;
+    for (;;) {
+        const bool at_work = i + 1 < n;
+        const u32 mine = at_work ? min(rd.safe_symbols(), n - 1 - i) : 0xFFFFFFFFu;
+        const u32 cnt = __builtin_amdgcn_readfirstlane(af_wave_min(mine));
+        if (cnt == 0xFFFFFFFFu || cnt < 16) break;
+        if (at_work) {
+            const u32 *before = rd.ptr;
+            for (u32 u = 0; u < cnt; ++u) {
+                step(i + u);
+                renorm(std::true_type{});
+            }
+            rd.settle(before);
+        }
+        i += cnt;
     }
-    step(i);  // i = n - 1
+    for (; i + 1 < n; ++i) {
+        step(i);
+        renorm(std::false_type{});
+    }
+    step(n - 1);
     so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;

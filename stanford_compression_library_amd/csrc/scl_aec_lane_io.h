@@ -139,7 +139,17 @@ struct AfReader {
 
     // The word in `ahead` becomes part of the window; bits past the end of the stream read as zero (the arithmetic
     // decoder looks PRECISION bits ahead, arithmetic_coding.py:222-229), and no load goes past the stream's last word.
+    // UNCHECKED: for a stretch of symbols over which the caller has established that no lane reaches the last word of its
+    // stream (safe_symbols below): no mask, no counter -- six instructions instead of twelve.  The caller settles `left`
+    // afterwards (settle).
+    template <bool UNCHECKED = false>
     __device__ __forceinline__ u32 next_word() {
+        if (UNCHECKED) {
+            const u32 v = __builtin_bswap32(ahead);
+            ptr += 1;
+            ahead = *ptr;
+            return v;
+        }
         const bool more = left > 1u;
         const u32 v = __builtin_bswap32(ahead) & (more ? 0xFFFFFFFFu : tail);
         tail = more ? tail : 0u;
@@ -148,6 +158,10 @@ struct AfReader {
         ahead = *ptr;
         return v;
     }
+    // number of symbols this lane can decode with the unchecked refill: a symbol takes at most two words (closed form: <= 31
+    // bits; the literal loops of a corner: <= 63), and the last word of the stream must not be reached
+    __device__ __forceinline__ u32 safe_symbols() const { return left ? (left - 1u) >> 1 : 0u; }
+    __device__ __forceinline__ void settle(const u32 *ptr_before) { left -= (u32)(ptr - ptr_before); }
     __device__ __forceinline__ void init(const u8 *in, u64 in_size_bytes, u64 bit_off, u32 nbits) {
         const u64 nwords = in_size_bytes >> 2;  // readable 32-bit words
         const u64 wi = min(bit_off >> 5, nwords - 1);
@@ -167,22 +181,24 @@ struct AfReader {
         consume(skipb);  // drop the bits in front of the stream
     }
     __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(a, b, (u32)r); }  // the next 32 bits
+    template <bool UNCHECKED = false>
     __device__ __forceinline__ void consume(u32 nb) {  // nb <= 31
         r -= (int)nb;
         if (r < 0) {
             a = b;
-            b = next_word();
+            b = next_word<UNCHECKED>();
             r += 32;
         }
     }
+    template <bool UNCHECKED = false>
     __device__ __forceinline__ u32 get(u32 nb) {  // nb <= 32; headers, the first state and the literal loops
         const u32 l = look();
         if (nb == 32) {
             a = b;
-            b = next_word();
+            b = next_word<UNCHECKED>();
             return l;
         }
-        consume(nb);
+        consume<UNCHECKED>(nb);
         return nb ? l >> (32 - nb) : 0u;
     }
 };
@@ -190,13 +206,21 @@ struct AfReader {
 // the closed-form renormalisation's state update: kt = k + m <= 31 bits come in from the stream, the bit k steps below the
 // top is kept on top (the E3 steps), arithmetic_coding.py:245-275.  {state, look} << kt is one 64-bit shift and kt = 0 needs
 // no special case.
+template <bool UNCHECKED = false>
 __device__ __forceinline__ u32 af_state_shift_in(AfReader &rd, u32 state, u32 k, u32 kt) {
     u32 l = rd.look();
     asm volatile("" : "+v"(l));  // taken before the refill branch, so that a/b/r are updated in place there
     const u64 both = (((u64)state << 32) | l) << kt;
     const u32 keep = (state << k) & 0x80000000u;
-    rd.consume(kt);
+    rd.consume<UNCHECKED>(kt);
     return ((u32)(both >> 32) & 0x7FFFFFFFu) | keep;
+}
+
+// minimum of v over the lanes of the wave that execute this (all of them must: call it outside divergent control flow)
+__device__ __forceinline__ u32 af_wave_min(u32 v) {
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v = min(v, (u32)__shfl_xor((int)v, sft, 64));
+    return v;
 }
 
 // ---- decoded symbols: four to a word, sixteen words to a 64-byte sector staged in LDS ([thread][64 bytes]), stored as four
