@@ -17,6 +17,7 @@
 // 17 rows x 32 B x 256 lanes = 136 KiB: one workgroup per CU, one wave per SIMD, like scl_aec_fast.hip, whose
 // arithmetic (exact binary64 division, closed-form renormalisation) and per-lane I/O are reused unchanged.
 // The generic kernel scans the 256 counts twice per symbol: 0.38 GB/s round trip on bytes.
+#include <type_traits>
 #include "scl_aec_internal.h"
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
@@ -286,10 +287,9 @@ __global__ void __launch_bounds__(AI_THREADS)
         T += 1;
         so.put(s, i);  // symbol out: whole 64-byte sectors (AfSymOut)
     };
-    u32 i = 0;
-    for (; i + 1 < n; ++i) {
-        step(i);
-        // ---- renormalisation, :245-275 ----
+    // ---- renormalisation, :245-275; UNCHECKED selects the reader's refill (AfReader::next_word) ----
+    auto renorm = [&](auto unchecked) {
+        constexpr bool UC = decltype(unchecked)::value;
         u32 k, m, nlow, nhm;
         const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
@@ -304,14 +304,14 @@ __global__ void __launch_bounds__(AI_THREADS)
                     hi = (hi - AF_HALF) << 1;
                     stt = (stt - AF_HALF) << 1;
                 }
-                stt += rd.get(1);
+                stt += rd.get<UC>(1);
                 used++;
             }
             while (lo > AF_QTR && hi < 3ull * AF_QTR) {
                 lo = (lo - AF_QTR) << 1;
                 hi = (hi - AF_QTR) << 1;
                 stt = (stt - AF_QTR) << 1;
-                stt += rd.get(1);
+                stt += rd.get<UC>(1);
                 used++;
             }
             low = (u32)lo;
@@ -319,13 +319,36 @@ __global__ void __launch_bounds__(AI_THREADS)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            state = af_state_shift_in(rd, state, k, kt);
+            state = af_state_shift_in<UC>(rd, state, k, kt);
             low = nlow;
             hm = nhm;
             used += kt;
         }
+    
+    };
+    // Stretches of symbols with the unchecked refill and a scalar trip count, then the checked loop for the chunks' last
+    // symbols: as in scl_aec_fast.hip (the symbol index i is the same for every lane still at work).
+    u32 i = 0;
+    for (;;) {
+        const bool at_work = i + 1 < n;
+        const u32 mine = at_work ? min(rd.safe_symbols(), n - 1 - i) : 0xFFFFFFFFu;
+        const u32 cnt = __builtin_amdgcn_readfirstlane(af_wave_min(mine));
+        if (cnt == 0xFFFFFFFFu || cnt < 16) break;
+        if (at_work) {
+            const u32 *before = rd.ptr;
+            for (u32 u = 0; u < cnt; ++u) {
+                step(i + u);
+                renorm(std::true_type{});
+            }
+            rd.settle(before);
+        }
+        i += cnt;
     }
-    step(i);  // i = n - 1
+    for (; i + 1 < n; ++i) {
+        step(i);
+        renorm(std::false_type{});
+    }
+    step(n - 1);
     so.finish(n);
     // how many of the last PRECISION bits belonged to the encoder (:277-282)
     const u64 lo = low, hi = (u64)hm + 1;
