@@ -122,8 +122,9 @@ __global__ void __launch_bounds__(AI_THREADS)
     auto code = [&](u32 cc, u32 dd, u32 TT, double xx) {
         af_shrink2(low, hm, cc, dd, xx);
         u32 k, m, nlow, nhm;
-        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
-        if (__builtin_expect(edge || (k + pending > 32), 0)) {
+        const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);  // the conservative corner test: two compares fewer
+        const bool rare = edge | (k + pending > 32);  // one condition, one branch
+        if (__builtin_expect(rare, 0)) {
             u64 lo = low, hi = (u64)hm + 1;
             while (hi < AF_HALF || lo > AF_HALF) {
                 if (hi < AF_HALF) {
@@ -147,15 +148,17 @@ __global__ void __launch_bounds__(AI_THREADS)
             low = (u32)lo;
             hm = (u32)(hi - 1);
         } else {
-            if (k > 0) {
-                const u32 top = low >> (32 - k);
-                const u32 b0 = top >> (k - 1);
-                const u32 rest = top & ((1u << (k - 1)) - 1u);
-                const u32 pat = (1u << pending) - (b0 ^ 1u);  // pending <= 31 here
-                wr.put((pat << (k - 1)) | rest, k + pending);
-                pending = 0;
-            }
-            pending += m;
+            // b0, then `pending` copies of !b0, then the other k - 1 common bits -- without a branch on k: for k = 0 the
+            // field is empty (v = 0, nb = 0) and the pending count just grows
+            const bool any = k != 0;
+            const u32 km1 = (k - 1u) & 31u;
+            const u32 b0 = low >> 31;
+            const u32 rest = __builtin_amdgcn_ubfe(low, (32u - k) & 31u, km1);  // bits 30 .. 32-k of low
+            const u32 pat = (1u << pending) - (b0 ^ 1u);                       // pending <= 31 here
+            u32 fv = (pat << km1) | rest, fn = k + pending;
+            asm volatile("" : "+v"(fv), "+v"(fn));  // computed for every lane: the compiler would turn the selects into a branch
+            wr.put_field(any ? fv : 0u, any ? fn : 0u);
+            pending = (any ? 0u : pending) + m;
             low = nlow;
             hm = nhm;
         }

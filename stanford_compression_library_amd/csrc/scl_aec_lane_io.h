@@ -106,6 +106,16 @@ struct AfWriterT {
             nacc = tot;
         }
     }
+    // put for the per-symbol field of the encoders (nb <= 32, nb = 0 allowed with v = 0): the pending bits and the field
+    // side by side in 64 bits, so that only the completed word is conditional -- no "which half" case split, no values
+    // merged after a branch (put above costs the lone wave ~8 register copies per symbol for those).
+    __device__ __forceinline__ void put_field(u32 v, u32 nb) {
+        const u32 tot = nacc + nb;                    // <= 63
+        const u64 wide = ((u64)hi << nb) | v;         // tot valid bits, right-aligned
+        nacc = tot & 31u;
+        if (tot >= 32) emit(__builtin_bswap32((u32)(wide >> nacc)));  // tot - 32 = tot & 31 here
+        hi = (u32)wide & ((1u << nacc) - 1u);
+    }
     __device__ __forceinline__ void put_run(u32 bit, u32 count) {
         while (count >= 32) {
             put(bit ? 0xFFFFFFFFu : 0u, 32);
