@@ -52,8 +52,9 @@ __device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending
     else
         af_shrink2(low, hm, c, d, xT);
     u32 k, m, nlow, nhm;
-    const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
-    if (__builtin_expect(edge || (k + pending > 32), 0)) {
+    const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);  // the conservative corner test: two compares fewer
+    const bool rare = edge | (k + pending > 32);                 // one condition, one branch
+    if (__builtin_expect(rare, 0)) {
         u64 lo = low, hi = (u64)hm + 1;
         while (hi < AF_HALF || lo > AF_HALF) {
             if (hi < AF_HALF) {
@@ -78,16 +79,17 @@ __device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending
         low = (u32)lo;
         hm = (u32)(hi - 1);
     } else {
-        if (k > 0) {
-            // b0, then `pending` copies of !b0, then the other k-1 common bits
-            const u32 top = low >> (32 - k);
-            const u32 b0 = top >> (k - 1);
-            const u32 rest = top & ((1u << (k - 1)) - 1u);
-            const u32 pat = (1u << pending) - (b0 ^ 1u);  // pending <= 31 here
-            wr.put(lds, (pat << (k - 1)) | rest, k + pending);
-            pending = 0;
-        }
-        pending += m;
+        // b0, then `pending` copies of !b0, then the other k - 1 common bits -- without a branch on k: for k = 0 the field is
+        // empty (v = 0, nb = 0) and the pending count just grows (as in scl_aec_iid.hip)
+        const bool any = k != 0;
+        const u32 km1 = (k - 1u) & 31u;
+        const u32 b0 = low >> 31;
+        const u32 rest = __builtin_amdgcn_ubfe(low, (32u - k) & 31u, km1);  // bits 30 .. 32-k of low
+        const u32 pat = (1u << pending) - (b0 ^ 1u);                       // pending <= 31 here
+        u32 fv = (pat << km1) | rest, fn = k + pending;
+        asm volatile("" : "+v"(fv), "+v"(fn));  // computed for every lane: the compiler would turn the selects into a branch
+        wr.put_field(lds, any ? fv : 0u, any ? fn : 0u);
+        pending = (any ? 0u : pending) + m;
         low = nlow;
         hm = nhm;
     }
@@ -208,8 +210,9 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     auto decode_symbol = [&](bool last) -> u32 {
         const double xr = af_recip((double)(hm - low) + 1.0);
         const double num = __builtin_fma((double)(state - low) + 1.0, Td, -0.5);
-        u32 tgt = (u32)(num * xr);  // ((state - low + 1) * T - 1) // rng, see scl_aec.hip
-        tgt = min(tgt, P.T - 1);
+        // ((state - low + 1) * T - 1) // rng, see scl_aec.hip.  low <= state <= hm holds for ANY input bits (the symbol chosen
+        // is the one whose interval holds the state), so target <= T - 1: no clamp
+        const u32 tgt = (u32)(num * xr);
         u32 s;
         if (LUT) {
             s = *reinterpret_cast<const u8 *>(lds + AS_LUT_BASE + tgt);
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             af_shrink2(low, hm, e.x, e.y, xT);
         if (last) return s;
         u32 k, m, nlow, nhm;
-        const bool edge = af_renorm2(low, hm, k, m, nlow, nhm);
+        const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);
         if (__builtin_expect(edge, 0)) {
             u64 lo = low, hi = (u64)hm + 1, stt = state;
             while (hi < AF_HALF || lo > AF_HALF) {
@@ -258,11 +261,11 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             state = (u32)stt;
         } else {
             const u32 kt = k + m;  // <= 31
-            const u32 lk = rd.look();
-            const u32 bits = (lk >> 1) >> (31 - kt);  // the next kt bits (kt may be 0)
-            rd.advance(lds, kt);
+            // kt bits come in from the stream: {state, look} << kt in one 64-bit shift (kt may be 0)
+            const u64 both = (((u64)state << 32) | rd.look()) << kt;
             const u32 keep = (state << k) & AF_HALF;
-            state = (((state << kt) | bits) & 0x7FFFFFFFu) | keep;
+            rd.advance(lds, kt);
+            state = ((u32)(both >> 32) & 0x7FFFFFFFu) | keep;
             low = nlow;
             hm = nhm;
             used += kt;

@@ -939,6 +939,21 @@ struct AnsFwdWriter {
             nacc = tot;
         }
     }
+    // put for the per-symbol field of the arithmetic encoders (w <= 32; w = 0 allowed with v = 0): pending bits and field side
+    // by side in 64 bits, only the completed word is conditional -- no case split on which half the word comes from and no
+    // values merged after a branch.  (The round-1 fault blamed on this 64-bit form was a register spill --
+    // profiles/r03_fwd_writer_fault_analysis.txt; no kernel spills now, tests/test_no_scratch.py.)
+    __device__ __forceinline__ void put_field(char *lds, u32 v, u32 w) {
+        const u32 tot = nacc + w;              // <= 63
+        const u64 wide = ((u64)hi << w) | v;   // tot valid bits, right-aligned
+        nacc = tot & 31u;
+        if (tot >= 32) {
+            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32((u32)(wide >> nacc));  // tot - 32 = tot & 31 here
+            ra = (ra + THREADS * 4) & (RING_BYTES - 1);
+            ++pend;
+        }
+        hi = (u32)wide & ((1u << nacc) - 1u);
+    }
     // 16 pending words leave the ring at a time; call after at most 16 new words
     __device__ __forceinline__ void maybe_flush(char *lds) {
         if (pend >= 16) {
