@@ -240,8 +240,10 @@ __global__ void __launch_bounds__(AS_THREADS)
                     u32 m = (u32)__builtin_clz(~z);
                     const u32 kt = k + m;  // <= 31
                     const u32 nlow = (low << kt) & 0x7FFFFFFFu;
-                    const u32 nhm = (hm << kt) | ((1u << kt) - 1u) | AF_HALF;
-                    const bool edge = (nlow == 0 && low != 0) || (nhm == 0xFFFFFFFFu && hm != 0xFFFFFFFFu);
+                    const u32 nhm = ~(~hm << kt) | AF_HALF;  // (hm << kt) | ones(kt) | HALF
+                    // the conservative form of the corner test (af_renorm2_dec): the first symbols of a chunk, coded while
+                    // low is still 0 or high still 2^32, take the literal loops as well -- two compares fewer on all others
+                    const bool edge = nlow == 0 || nhm == 0xFFFFFFFFu;
                     u32 top;
                     if (__builtin_expect(edge, 0)) {
                         u64 lo = low, hi = (u64)hm + 1;
