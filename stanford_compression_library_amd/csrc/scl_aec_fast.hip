@@ -256,6 +256,9 @@ __global__ void __launch_bounds__(AF_THREADS)
 // Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
 // back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
+#ifndef AD_QUADS
+#define AD_QUADS 1  // the unchecked stretches of the decoder in groups of four symbols
+#endif
 #ifndef AD_XT_PLACE
 #define AD_XT_PLACE 1  // 1: 1/T between the search and the wait for c, d; 0: wherever the compiler puts it (the top)
 #endif
@@ -314,7 +317,6 @@ __global__ void __launch_bounds__(AF_THREADS)
     }
     AfSymOut so;
     so.init(lds + AD_OUT_BASE, tid, out_sym + chunk * out_stride);
-    u64 used = 32;
     u32 state = rd.get(32);
     u32 low = 0, hm = 0xFFFFFFFFu;
     u32 ctx = 0;
@@ -389,14 +391,12 @@ __global__ void __launch_bounds__(AF_THREADS)
                     stt = (stt - AF_HALF) << 1;
                 }
                 stt += rd.get<UC>(1);
-                used++;
             }
             while (lo > AF_QTR && hi < 3ull * AF_QTR) {
                 lo = (lo - AF_QTR) << 1;
                 hi = (hi - AF_QTR) << 1;
                 stt = (stt - AF_QTR) << 1;
                 stt += rd.get<UC>(1);
-                used++;
             }
             low = (u32)lo;
             hm = (u32)(hi - 1);
@@ -406,7 +406,6 @@ __global__ void __launch_bounds__(AF_THREADS)
             state = af_state_shift_in<UC>(rd, state, k, kt);
             low = nlow;
             hm = nhm;
-            used += kt;
         }
     };
     // The symbol index i is the same for every lane still at work (they start together and only drop out), so it lives in a
@@ -421,10 +420,34 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (cnt == 0xFFFFFFFFu || cnt < 16) break;
         if (at_work) {
             const u32 *before = rd.ptr;
+#if AD_QUADS
+            // four symbols per trip once the index is a multiple of four: which byte of the output word a symbol fills, and
+            // when the word is complete, are then known at compile time (AfSymOut::put: no scalar compare-and-branch per
+            // symbol), and the trip count is tested once per four
+            u32 u = 0;
+            for (; u < cnt && ((i + u) & 3u); ++u) {
+                step(i + u);
+                renorm(std::true_type{});
+            }
+            for (; u + 4 <= cnt; u += 4) {
+                const u32 base = i + u;
+                __builtin_assume((base & 3u) == 0);
+#pragma unroll
+                for (u32 q = 0; q < 4; ++q) {
+                    step(base + q);
+                    renorm(std::true_type{});
+                }
+            }
+            for (; u < cnt; ++u) {
+                step(i + u);
+                renorm(std::true_type{});
+            }
+#else
             for (u32 u = 0; u < cnt; ++u) {
                 step(i + u);
                 renorm(std::true_type{});
             }
+#endif
             rd.settle(before);
         }
         i += cnt;
@@ -443,7 +466,7 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (slo < lo || shi > hi) break;
     }
     if (e == 32) e = 31;
-    consumed[chunk] = (u32)((i64)(used + P.size_bits) - ((i64)e - 1));
+    consumed[chunk] = (u32)((i64)rd.position() - ((i64)e - 1));
     if (status) status[chunk] = st;
 }
 

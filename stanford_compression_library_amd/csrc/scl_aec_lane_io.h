@@ -146,6 +146,9 @@ struct AfReader {
     int r;
     u32 left;        // words of the stream not yet moved into a/b, the partial last one included, clipped to the buffer
     u32 tail;        // mask of the stream's bits in its last word (all ones if it ends on a word boundary); 0 once used
+    const u32 *ptr0; // position(): ptr at init,
+    u32 past;        //             refills that did not advance ptr (at and past the end of the stream),
+    u32 skip;        //             bits in front of the stream in its first word
 
     // The word in `ahead` becomes part of the window; bits past the end of the stream read as zero (the arithmetic
     // decoder looks PRECISION bits ahead, arithmetic_coding.py:222-229), and no load goes past the stream's last word.
@@ -163,6 +166,7 @@ struct AfReader {
         const bool more = left > 1u;
         const u32 v = __builtin_bswap32(ahead) & (more ? 0xFFFFFFFFu : tail);
         tail = more ? tail : 0u;
+        past += more ? 0u : 1u;
         left = left ? left - 1u : 0u;
         ptr = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(ptr) + (more ? 4 : 0));
         ahead = *ptr;
@@ -184,12 +188,18 @@ struct AfReader {
         tail = (left < swords) ? 0xFFFFFFFFu : (tb ? ~(0xFFFFFFFFu >> tb) : 0xFFFFFFFFu);
         if (left == 0) tail = 0;
         ptr = reinterpret_cast<const u32 *>(in) + wi;
+        ptr0 = ptr;
+        past = 0;
+        skip = skipb;
         ahead = *ptr;
         a = 0;
         b = next_word();
         r = 0;
         consume(skipb);  // drop the bits in front of the stream
     }
+    // bits of the stream consumed so far: every refill moved 32 bits in (ptr advanced, or `past` counted it), r + 32 are unread.
+    // The decoders derive num_bits_consumed from this at the end instead of adding up k + m symbol by symbol.
+    __device__ __forceinline__ u32 position() const { return 32u * ((u32)(ptr - ptr0) + past) - 32u - (u32)r - skip; }
     __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(a, b, (u32)r); }  // the next 32 bits
     template <bool UNCHECKED = false>
     __device__ __forceinline__ void consume(u32 nb) {  // nb <= 31
