@@ -12,9 +12,12 @@ run MODEL=rans REPS=60
 run MODEL=rans_b8 REPS=40
 run MODEL=tans REPS=30
 run MODEL=range REPS=15
-run MODEL=order1 REPS=40
-run MODEL=iid NCHUNKS=65536 REPS=10
-run MODEL=fixed REPS=10
+run MODEL=order1 REPS=60
+run MODEL=iid NCHUNKS=65536 REPS=60
+run MODEL=iid NCHUNKS=262144 REPS=10
+run MODEL=fixed REPS=40
+run MODEL=fixed_k64 REPS=10
+run MODEL=order1_k256 NCHUNKS=65536 REPS=3
 run MODEL=rans_k64 REPS=10
 run MODEL=rans_m3000 REPS=10
 echo >> $O; echo "randomised model tests (tests/test_gpu_batch.py -k random; SCL_RANDOM_SEEDS=${SEEDS:-1500})" >> $O
