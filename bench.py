@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--num-bits-out", type=int, default=1, help="rANS NUM_BITS_OUT (reference default 1)")
     ap.add_argument("--range-factor", type=int, default=1 << 16, help="rANS RANGE_FACTOR (reference default 2^16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-pipeline", action="store_true",
+                    help="skip the two-sub-batch pipelined dense encode (roofline_dense.pipelined_ms): it launches the encode "
+                         "kernel on HALF batches, which a profiler's per-kernel means would mix with the full-size launches")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline only (the default 1-GPU run also measures configs[1..3], see the docstring)")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
@@ -502,7 +505,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
         # the same result as ONE pipelined operation: two sub-batches on two streams, the compaction of the first running
         # while the second is encoded (backend/models.py DensePipeline; scl_streams_compact_at keeps the offsets on the
         # device).  Timed as a whole -- encode included -- and checked byte for byte against the sequential result.
-        if not model._needs_scratch and n_chunks >= 4096:
+        if not model._needs_scratch and n_chunks >= 4096 and not getattr(w, "no_dense_pipeline", False):
             wd.enter(f"{w.coder}: pipelined dense encode")
             pipe = _m.DensePipeline(model, n_chunks, chunk_len, dev, n_sub=2)
             p_dense, p_offs = pipe.run(sym)

@@ -20,6 +20,7 @@ run range_markov1 --coder range --source markov1 --no-cpu-baseline
 run aec_static --coder aec --aec-model fixed
 run aec_iid --coder aec --aec-model iid --chunks 65536
 run aec_k256_256Ki --coder aec --aec-K 256 --chunks 262144 --steps 2 --warmup 1 --no-cpu-baseline
+[ "${PART:-all}" = "lines" ] && exit 0   # PART=lines: only the bench lines above (after traffic.json was refreshed)
 for spec in "rans_headline:" "rans_markov1:--source markov1" "config2_64Ki:--chunks 65536" "tans:--coder tans" \
             "range_uniform1:--coder range --table uniform1" "range_t256:--coder range --table t256" \
             "rans_b8:--num-bits-out 8 --range-factor 256" "aec_k16:--coder aec --steps 5 --warmup 2" \

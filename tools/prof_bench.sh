@@ -10,8 +10,9 @@ OUT=$REPO/gpurun_out/prof_$NAME
 RAW=/tmp/prof_raw_$NAME
 rm -rf $RAW $OUT; mkdir -p $OUT $RAW
 python $REPO/bench.py --no-cpu-baseline --no-other-configs ${BENCH_ARGS} 2>/dev/null | grep '^{' > $OUT/bench.json
-TRACE_CMD="python $REPO/bench.py --no-cpu-baseline --no-other-configs ${BENCH_ARGS}"
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --min-warm-ms 0 --no-cpu-baseline --no-other-configs ${BENCH_ARGS}"
+# (--no-dense-pipeline: that measurement launches the encode kernel on half batches; per-kernel means must not mix them in)
+TRACE_CMD="python $REPO/bench.py --no-cpu-baseline --no-other-configs --no-dense-pipeline ${BENCH_ARGS}"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --min-warm-ms 0 --no-cpu-baseline --no-other-configs --no-dense-pipeline ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $TRACE_CMD > $OUT/trace.log 2>&1
 find $RAW/trace -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find $RAW/trace -name '*kernel_trace.csv' -exec python3 $REPO/tools/summarize_trace.py {} $OUT/kernel_trace_summary.txt \;
