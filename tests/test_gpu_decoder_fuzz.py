@@ -173,3 +173,28 @@ def test_damaged_streams(name, kind, monkeypatch):
             # 222-229, 258-261 -- and may well finish; the ANS and range decoders consume every bit the encoder wrote)
             cut = damaged & (in_nbits < nbits)
             assert (st[cut] != 0).all(), f"{name}: a stream cut short decoded without any status bit"
+
+
+@pytest.mark.parametrize("name", ["aec_lds_k16", "aec_iid256", "aec_static", "aec_sparse_k256"])
+@pytest.mark.parametrize("nbytes", [1, 3, 4, 7])
+def test_input_buffers_of_a_few_bytes(name, nbytes):
+    """The tuned arithmetic decoders load whole 32-bit words: a buffer shorter than one word goes to the any-parameter kernel
+    (scl_aec_decode_batch), a buffer of one or two words must not be read past its end.  Either way: a status, no fault."""
+    from stanford_compression_library_amd.backend import lib
+
+    lib.require_device()
+    dev = torch.device("cuda:0")
+    model = _families()[name]["make"]()
+    n_chunks = 70
+    arena = Arena(1 << 20, dev)
+    d_in = arena.take(nbytes)
+    d_in.copy_(torch.arange(nbytes, dtype=torch.uint8) * 37 + 11)
+    offs = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+    nb = torch.full((n_chunks,), 8 * nbytes, dtype=torch.int32, device=dev)
+    nb[1::2] = 200  # a lie: more bits than the buffer holds
+    sym, lens, used, status = model.decode_batch(d_in, offs, nb, 64)
+    torch.cuda.synchronize()
+    arena.check(f"{name} {nbytes}-byte input")
+    st = status.cpu().numpy().astype(np.uint32)
+    assert not (st & ~np.uint32(ALLOWED)).any()
+    assert (lens.cpu().numpy()[st == 0] <= 64).all()
