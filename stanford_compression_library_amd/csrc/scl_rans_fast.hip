@@ -405,6 +405,21 @@ __device__ __forceinline__ u32 rf_decode_symbol(u32 &x, u32 &lk, u32 &used, cons
         used = cl;
         return e.x;
     }
+    if (ML_T == 0 && CB_T == 3) {
+        // The same with run-time constants, for every power-of-two total and every RANGE_FACTOR with NUM_STATE_BITS <= 29
+        // (tANS at its default RANGE_FACTOR = 1 among them): the state is carried as X = x << 3 (not top-aligned any more,
+        // but the table offset is still X & (8 (M - 1))), and the renormalising shift that also re-aligns is by
+        // (clz(xn) - cbl) + 3 -- cb_rt carries 3 - cbl here: one v_add on top of the literal form above, two instructions
+        // less than the form below.
+        const uint2 e = *reinterpret_cast<const uint2 *>(tab + (x & (((1u << ml_rt) - 1u) << 3)));
+        const u32 xn = __umul24(x >> (ml_rt + 3), e.x) + e.y;
+        const u32 cl = (u32)__builtin_clz(xn) + cb_rt;  // 3 <= cl <= 31
+        const u64 t = ((((u64)xn) << 32) | lk) << cl;
+        x = (u32)(t >> 32);
+        lk = __builtin_amdgcn_alignbit(x, (u32)t, 3);
+        used = cl;
+        return e.x;
+    }
     if (ML_T < 0) {
         // any total M <= 4096 (ml_rt carries nothing here; the run-time values come through rf_gen):
         //   x // M exactly as trunc((x + 0.5) * (1 / M)) in binary64 (x < 2^31, M <= 2^12: the error 2^-20 is far
@@ -455,7 +470,7 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
             // two symbols use at most 2*m <= 24 bits of the 32-bit lookahead (2 x 16 for NUM_BITS_OUT > 1: the second
             // symbol's three don't-care bits are whatever follows); the top-aligned variants report their shift, 3 more
             // per symbol than they read
-            r.advance(lds, ((ML_T > 0 && CB_T == 3) || NB_T != 1) ? ua + ub - 6u : ua + ub);
+            r.advance(lds, ((ML_T >= 0 && CB_T == 3) || NB_T != 1) ? ua + ub - 6u : ua + ub);
 #if RD_PERM_PAIRS
             // the symbol bytes of a pair with ONE v_perm (the earlier symbol is the more significant byte), the two pairs
             // of a word with another: three instead of four per four symbols
@@ -502,7 +517,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
     const u32 M = P.M;
-    constexpr u32 XSH = ((ML_T > 0 && CB_T == 3) || NB_T != 1) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
+    constexpr u32 XSH = ((ML_T >= 0 && CB_T == 3) || NB_T != 1) ? 3u : 0u;  // top-aligned state, see rf_decode_symbol
     for (u32 i = threadIdx.x; i < M; i += THREADS) {
         const uint2 v = P.d_dec_tab[i];
         reinterpret_cast<uint2 *>(s_lds)[i] = v;
@@ -529,7 +544,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
         n = 0;
     }
     const u32 st_header = st;
-    const u32 ml_rt = P.m_log2, cb_rt = 32 - P.nsb;
+    const u32 ml_rt = P.m_log2, cb_rt = (ML_T == 0 && CB_T == 3) ? 3u - (32 - P.nsb) : 32 - P.nsb;  // see rf_decode_symbol
     RfGenM rf_gen;
     rf_gen.inv_m = 1.0 / (double)P.M;
     rf_gen.m = NB_T != 1 ? P.dec_sadd : P.M;   // NUM_BITS_OUT > 1: b - 1 - cbl and ~(b - 1), see rf_decode_symbol
@@ -814,6 +829,8 @@ void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_siz
         if (big) RF_LAUNCH_DEC(-1, 0, RD_THREADS); else RF_LAUNCH_DEC(-1, 0, RD_THREADS_SMALL);
     } else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29) {
         if (big) RF_LAUNCH_DEC(12, 3, RD_THREADS); else RF_LAUNCH_DEC(12, 3, RD_THREADS_SMALL);
+    } else if (m->fdev.nsb <= 29) {  // the state fits shifted left by three (rf_decode_symbol)
+        if (big) RF_LAUNCH_DEC(0, 3, RD_THREADS); else RF_LAUNCH_DEC(0, 3, RD_THREADS_SMALL);
     } else {
         if (big) RF_LAUNCH_DEC(0, 0, RD_THREADS); else RF_LAUNCH_DEC(0, 0, RD_THREADS_SMALL);
     }
