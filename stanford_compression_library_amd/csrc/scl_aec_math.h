@@ -86,6 +86,17 @@ __device__ __forceinline__ void af_shrink_pow2(u32 &low, u32 &hm, u32 c, u32 d, 
     low = low + q1;
 }
 
+// the same with c and d already zero-extended to 64 bits in register pairs (their low words are the multiplicands)
+__device__ __forceinline__ void af_shrink_pow2_wide(u32 &low, u32 &hm, u64 c, u64 d, u32 t) {
+    const u32 r1 = hm - low;
+    const u64 p1 = (u64)r1 * (u32)c + c;
+    const u64 p2 = (u64)r1 * (u32)d + d;
+    const u32 q1 = __builtin_amdgcn_alignbit((u32)(p1 >> 32), (u32)p1, t);
+    const u32 q2 = __builtin_amdgcn_alignbit((u32)(p2 >> 32), (u32)p2, t);
+    hm = low + q2 - 1u;
+    low = low + q1;
+}
+
 // closed-form step counts AND the renormalised interval; true if the literal loops must be used for this symbol.
 // The corner test of af_renorm_counts on the SHIFTED values: ctz(low) + k + m + 1 >= 32 with low != 0 <=> every bit of
 // low leaves, i.e. (low << (k + m)) & 0x7FFFFFFF == 0; for high = hm + 1 != 2^32: (high << (k + m + 1)) mod 2^32 == 0 <=>

@@ -40,17 +40,29 @@ __device__ __forceinline__ void as_setup_tables(char *lds, const AecStaticDev &P
     __syncthreads();
 }
 
+// The ENCODER's table for power-of-two totals: 16-byte entries {c, 0, d, 0} -- both counts arrive zero-extended to 64 bits in
+// aligned register pairs, which is how v_mad_u64_u32 (af_shrink_pow2_wide) takes its addend: four register copies per symbol
+// otherwise.  (36 KiB of LDS per workgroup: still four per CU.  The decoder has no room for it next to its slot table.)
+__device__ __forceinline__ void as_setup_table16(char *lds, const AecStaticDev &P, u32 tid) {
+    if (tid < P.K) {
+        const u32 c = P.d_cum[tid], f = P.d_freq[tid];
+        *reinterpret_cast<uint4 *>(lds + AS_TAB_BASE + tid * 16) = make_uint4(c, 0u, c + f, 0u);
+    } else if (tid < 256) {
+        *reinterpret_cast<uint4 *>(lds + AS_TAB_BASE + tid * 16) = make_uint4(0u, 0u, 1u, 0u);  // never selected
+    }
+    __syncthreads();
+}
 typedef AnsFwdWriter<AS_THREADS> AsOut;
 typedef AnsBitReader<AS_THREADS, true> AsIn;
 
 // one symbol of the encoder: shrink_range, then the renormalisation loops (:126-150)
 template <bool POW2>
-__device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending, u32 c, u32 d, u32 t, double xT,
+__device__ __forceinline__ void as_encode_symbol(u32 &low, u32 &hm, u32 &pending, u64 c, u64 d, u32 t, double xT,
                                                  AsOut &wr, char *lds) {
     if (POW2)
-        af_shrink_pow2(low, hm, c, d, t);
+        af_shrink_pow2_wide(low, hm, c, d, t);
     else
-        af_shrink2(low, hm, c, d, xT);
+        af_shrink2(low, hm, (u32)c, (u32)d, xT);
     u32 k, m, nlow, nhm;
     const bool edge = af_renorm2_dec(low, hm, k, m, nlow, nhm);  // the conservative corner test: two compares fewer
     const bool rare = edge | (k + pending > 32);                 // one condition, one branch
@@ -101,9 +113,12 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
     aec_static_encode_kernel(AecStaticDev P, const u8 *__restrict__ sym, u64 sym_stride, const u32 *__restrict__ lens,
                              u32 chunk_len, u64 n_chunks, u8 *__restrict__ out, u64 out_stride,
                              u64 *__restrict__ out_bit_off, u32 *__restrict__ out_nbits, u32 *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) char lds[AS_TAB_BASE + 2048];
+    __shared__ __attribute__((aligned(16))) char lds[AS_TAB_BASE + (POW2 ? 4096 : 2048)];
     const u32 tid = threadIdx.x;
-    as_setup_tables(lds, P, tid, false);
+    if (POW2)
+        as_setup_table16(lds, P, tid);
+    else
+        as_setup_tables(lds, P, tid, false);
     const u64 chunk = (u64)blockIdx.x * AS_THREADS + tid;
     if (chunk >= n_chunks) return;
     const u32 n = lens ? lens[chunk] : chunk_len;
@@ -121,8 +136,13 @@ __global__ void __launch_bounds__(AS_THREADS, 4)
             w >>= 8;
             bad = max(bad, s);
             s = (s < P.K) ? s : 0u;
-            const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_TAB_BASE + s * 8);
-            as_encode_symbol<POW2>(low, hm, pending, e.x, e.y, P.t, xT, wr, lds);
+            if (POW2) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(lds + AS_TAB_BASE + s * 16);  // {c, 0, d, 0}
+                as_encode_symbol<POW2>(low, hm, pending, e.x | ((u64)e.y << 32), e.z | ((u64)e.w << 32), P.t, xT, wr, lds);
+            } else {
+                const uint2 e = *reinterpret_cast<const uint2 *>(lds + AS_TAB_BASE + s * 8);
+                as_encode_symbol<POW2>(low, hm, pending, e.x, e.y, P.t, xT, wr, lds);
+            }
         }
         wr.maybe_flush(lds);  // <= 4 new words per fast-path call on top of <= 15 pending (ring of 32)
     };
