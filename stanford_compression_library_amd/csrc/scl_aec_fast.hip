@@ -256,6 +256,10 @@ __global__ void __launch_bounds__(AF_THREADS)
 // Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
 // back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
+#ifndef AD_CD_SPLIT
+#define AD_CD_SPLIT 1  // c and d as two 2-byte LDS reads; 0: one 4-byte read at a 2-byte-aligned address (legal, and what the
+                       // compiler makes of two adjacent reads on its own -- but 3.6 % slower: 5.63 against 5.42 ms)
+#endif
 #ifndef AD_QUADS
 #define AD_QUADS 1  // the unchecked stretches of the decoder in groups of four symbols
 #endif
@@ -344,10 +348,15 @@ __global__ void __launch_bounds__(AF_THREADS)
         // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
         // the row, masked away below.  All addresses of the step hang off "row - 2": one add fewer than with "row" and "- 2".
         const u32 ea_m2 = row_m2 + 2 * s;
-        // (one 4-byte read at a 2-byte-aligned address: LDS accesses need no alignment on gfx950 under amdhsa -- the compiler
-        // merges two adjacent 2-byte reads into exactly this on its own)
+#if AD_CD_SPLIT
+        u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea_m2);
+        u32 ea_d = ea_m2;
+        asm("" : "+v"(ea_d));  // hides that the two reads are adjacent (the compiler would merge them into one unaligned read)
+        u32 d_raw = *reinterpret_cast<const u16_lds *>(lds + ea_d + 2);
+#else
         u32 cd;
         __builtin_memcpy(&cd, lds + ea_m2, 4);
+#endif
         // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
         *reinterpret_cast<uint4_lds *>(lds + row_m2 + 2) =
             make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
@@ -364,6 +373,11 @@ __global__ void __launch_bounds__(AF_THREADS)
 #endif
         double xT = af_recip_fd(T2, Td);
         asm volatile("" : "+v"(xT));
+#if AD_CD_SPLIT
+        asm volatile("" : "+v"(c_raw), "+v"(d_raw));
+        const u32 c = c_raw & ~msk[0];
+        af_shrink2_d(low, hm, (double)c, (double)d_raw, xT);
+#else
         asm volatile("" : "+v"(cd));
         // c = low half, 0 for s = 0 (<=> Y[0] > target <=> the low half of msk[0] is all ones); d = high half, converted
         // straight out of the pair (d < 2^15: exact as float)
@@ -371,6 +385,7 @@ __global__ void __launch_bounds__(AF_THREADS)
         float df;
         asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(df) : "v"(cd));
         af_shrink2_d(low, hm, (double)c, (double)df, xT);
+#endif
         so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
     };
     // ---- renormalisation, :245-275; UNCHECKED selects the reader's refill (AfReader::next_word) ----
