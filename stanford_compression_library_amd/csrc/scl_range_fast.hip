@@ -141,9 +141,12 @@ struct RgDivM {
 // no table at all), 3 = the same with t = 0 as a compile-time fact (f = 1, M = 256: configs[2], uniform bytes -- two
 // shifts by zero less per decoded symbol, one per encoded symbol)
 #define RG_UNI(MODE) ((MODE) == 2 || (MODE) == 3)
+// encoder modes 4 and 5 = 0 and 1 for totals >= 256: range // M < 2^24, so c r and r f are 24-bit multiplies (full rate)
+// instead of v_mad_u64_u32 + v_mul_lo_u32 (quarter rate each)
+#define RG_R24(MODE) ((MODE) == 4 || (MODE) == 5)
 template <int MODE>
 __device__ __forceinline__ u32 rg_range_over_m(u32 range, const RgDivM &md) {
-    if (MODE == 1) return (u32)(((double)range + 0.5) * md.inv_m);
+    if (MODE == 1 || MODE == 5) return (u32)(((double)range + 0.5) * md.inv_m);
     if (MODE == 3) return range >> 8;  // a literal shift: half the cost of one whose amount sits in an SGPR
     return range >> md.m_log2;
 }
@@ -171,6 +174,9 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
     if (RG_UNI(MODE)) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
         range0 = (MODE == 3) ? r : (r << md.t);
         low0 = __umul24(e.x, range0) + low;
+    } else if (RG_R24(MODE)) {
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(low0) : "v"(e.x), "v"(r), "v"(low));  // c, r < 2^24; c r <= range
+        range0 = __umul24(r, e.y);
     } else {
         low0 = low + e.x * r;  // c * r <= range: no overflow past MASK (carry-less coder)
         range0 = r * e.y;
@@ -483,7 +489,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     } else if (LUT) {  // one read: slot -> {c | s << 24, f}
         e = *reinterpret_cast<const uint2 *>(tab + q * 8);
         s = e.x >> 24;
-        e.x &= 0xFFFFFFu;
+        if (!DIV32) e.x &= 0xFFFFFFu;  // (the 24-bit multiply-add below does not see the symbol byte)
     } else {
         s = 0;
 #pragma unroll
@@ -498,6 +504,14 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         const u32 rf = (MODE == 3) ? rr : (rr << md.t);  // < 2^24, see rg_encode_symbol
         low = __umul24(s, rf) + low;
         range = rf;
+    } else if (DIV32) {
+        // totals >= 256: rr = range // M < 2^24, and c, f < 2^24 (the symbol byte on top of c is outside the 24 bits the
+        // instruction reads): two full-rate 24-bit multiplies instead of v_mad_u64_u32 + v_mul_lo_u32 (quarter rate each).
+        // c rr <= range and f rr <= range: no overflow (carry-less coder)
+        u32 nl;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(nl) : "v"(e.x), "v"(rr), "v"(low));
+        low = nl;
+        range = __umul24(rr, e.y);
     } else {
         low += e.x * rr;
         range = rr * e.y;
@@ -676,8 +690,11 @@ void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym
                        sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
     if (m->fdev.uni_t == 0) RG_LAUNCH_ENC(3);
     else if (m->fdev.uni_t != 0xFFFFFFFFu) RG_LAUNCH_ENC(2);
-    else if (m->fdev.m_log2 != 0xFFFFFFFFu) RG_LAUNCH_ENC(0);
-    else RG_LAUNCH_ENC(1);
+    else if (m->fdev.m_log2 != 0xFFFFFFFFu) {
+        if (m->fdev.M >= 256) RG_LAUNCH_ENC(4); else RG_LAUNCH_ENC(0);
+    } else {
+        if (m->fdev.M >= 256) RG_LAUNCH_ENC(5); else RG_LAUNCH_ENC(1);
+    }
 #undef RG_LAUNCH_ENC
 }
 

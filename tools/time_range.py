@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
-freq = np.ones(256, dtype=np.int64)
+from stanford_compression_library_amd import bench_data
+freq = bench_data.t256_table() if os.environ.get("TABLE") == "t256" else np.ones(256, dtype=np.int64)
 model = models.RangeModel(freq.tolist(), 32, 32)
 n_chunks, chunk_len = 262144, 4096
 sym = torch.randint(0, 256, (n_chunks, chunk_len), dtype=torch.uint8, device=dev)
