@@ -84,8 +84,9 @@ struct AecSplitDev {
 template <bool ORDER1>
 __device__ __forceinline__ u32 as_next_ctx(const AecSplitDev &P, u32 ctx, u32 s) {  // past_k[1:] + [s], :146-151
     if (ORDER1) return s;
-    const u32 v = ctx * P.K + s;
-    return v - ((v * P.ctx_magic) >> 16) * P.nctx;
+    // (24-bit multiplies: v < 272, magic <= 2^15, nctx <= 16 -- the 32-bit v_mul_lo_u32 is a quarter-rate instruction)
+    const u32 v = __umul24(ctx, P.K) + s;
+    return v - __umul24(__umul24(v, P.ctx_magic) >> 16, P.nctx);
 }
 
 template <bool ORDER1>
