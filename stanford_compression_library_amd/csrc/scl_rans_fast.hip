@@ -91,10 +91,17 @@ template <int MSH_T, int R_T, typename EncOut>
 __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns k
     // run-time form: msh_rt = MSH | pre << 8 | r << 16.  Tables so small that m < 32 - nsb would need a negative MSH;
     // they shift x left by pre = (32 - nsb) - m first (x << pre < 2^(32 - m)) and use MSH = 1.
-    const u32 mh = rf_umulhi(MSH_T ? x : (x << ((msh_rt >> 8) & 0xFFu)), e.rcp);
+    // MSH_T = -1 (round 4): such a table with the pre-shift folded into its reciprocals -- mulhi(x << pre, rcp) = mulhi(x,
+    // rcp << pre) when rcp << pre fits 32 bits, which it does for every table seen (rans_fast_build_tables checks) -- so
+    // neither the pre-shift nor the quotient shift by MSH - 1 = 0 is executed: two instructions less per symbol than the
+    // run-time form (tANS at its default RANGE_FACTOR = 1 is such a table).
+    const u32 mh = rf_umulhi((MSH_T != 0) ? x : (x << ((msh_rt >> 8) & 0xFFu)), e.rcp);
     u32 q0, pos;
-    if (MSH_T) {
-        static_assert(MSH_T == 0 || MSH_T + R_T < 32, "shift out of range");
+    if (MSH_T < 0) {
+        q0 = mh;
+        pos = mh >> ((msh_rt >> 16) + 1u);
+    } else if (MSH_T) {
+        static_assert(MSH_T <= 0 || MSH_T + R_T < 32, "shift out of range");
         q0 = mh >> (MSH_T - 1);
         pos = mh >> (MSH_T + R_T);  // = q0 >> (r + 1), straight from the product
     } else {
@@ -667,6 +674,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     const RansDev &D = m->dev;
     m->fast = 0;
     m->fdev.b = 1;
+    m->fdev.enc_folded = 0;
     m->fdev.dec_sadd = m->fdev.dec_notb = 0;
     if (D.b > 1) return rans_fast_build_tables_b(m, h_freq, h_cum);
     // any total 2 <= M <= 4096 (a power of two or not), NUM_BITS_OUT = 1, RANGE_FACTOR = 2^r <= 2^23, H < 2^31
@@ -687,6 +695,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     const u32 enc_msh = ((C >= 33) ? (C - 32) : (1u | ((33 - C) << 8))) | (r << 16);
     std::vector<uint4> enc(256);
     std::vector<uint2> dec(M);
+    bool foldable = true;
     u64 fixed_k_mass[32] = {0};  // total frequency of the symbols that ALWAYS release k bits (k_hi == k_lo), per k
     for (u32 s = 0; s < 256; ++s) {
         const u32 src = s < D.K ? s : 0;  // out-of-alphabet symbols are flagged, entry 0 keeps the lane sane
@@ -704,8 +713,17 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
         if (E < nsb + ceil_log2_u32(f) || E > 62) return SCL_OK;  // cannot happen (see above)
         const u64 rcp = ((1ull << E) + f - 1) / f;
         if (rcp >> 32) return SCL_OK;
+        if (C < 33 && ((rcp << (33 - C)) >> 32) != 0) foldable = false;
         enc[s] = make_uint4((u32)rcp, M - f, c, k_lo);
         if (s < D.K && k_hi == k_lo && k_lo < 32) fixed_k_mass[k_lo] += f;
+    }
+    // small tables (C <= 32: MSH = 1 after a pre-shift of x): fold the pre-shift into the reciprocals when they all fit
+    u32 enc_msh_final = enc_msh;
+    m->fdev.enc_folded = 0;
+    if (C < 33 && foldable) {
+        for (u32 s = 0; s < 256; ++s) enc[s].x <<= (33 - C);
+        enc_msh_final = 1u | (r << 16);
+        m->fdev.enc_folded = 1;
     }
     // lanes whose symbols nearly all release the same number of bits complete their words at the same steps
     // (a table of equal frequencies does so exactly): AnsBackWriterS has no defence against that, AnsBackWriterL has
@@ -728,7 +746,7 @@ int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cu
     m->fdev.m_log2 = D.m_log2;
     m->fdev.L = (u32)D.L;
     m->fdev.M = M;
-    m->fdev.enc_msh = enc_msh;
+    m->fdev.enc_msh = enc_msh_final;
     m->fdev.d_enc_tab = m->d_enc_tab;
     m->fdev.d_dec_tab = m->d_dec_tab;
     m->fast = 1;
@@ -765,10 +783,10 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
     // literal form: only without a pre-shift, and for the one (MSH, r) pair that is instantiated
-    const int msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : 0;
+    const int msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : (m->fdev.enc_folded ? -1 : 0);
     const bool slots = rf_use_slot_writer(m, n_chunks);
 #define RF_LAUNCH_ENC_W(OUT, CHECK, MSH)                                                                             \
-    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, (MSH ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, (MSH > 0 ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, \
                        st, m->fdev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off,    \
                        d_nbits, d_status)
 #define RF_LAUNCH_ENC(CHECK, MSH)                 \
@@ -793,11 +811,11 @@ void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_s
     }
     // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
     if (m->fdev.K <= 128) {
-        if (msh == 10) RF_LAUNCH_ENC(1, 10); else RF_LAUNCH_ENC(1, 0);
+        if (msh == 10) RF_LAUNCH_ENC(1, 10); else if (msh < 0) RF_LAUNCH_ENC(1, -1); else RF_LAUNCH_ENC(1, 0);
     } else if (m->fdev.K < 256) {
-        if (msh == 10) RF_LAUNCH_ENC(2, 10); else RF_LAUNCH_ENC(2, 0);
+        if (msh == 10) RF_LAUNCH_ENC(2, 10); else if (msh < 0) RF_LAUNCH_ENC(2, -1); else RF_LAUNCH_ENC(2, 0);
     } else {
-        if (msh == 10) RF_LAUNCH_ENC(false, 10); else RF_LAUNCH_ENC(false, 0);
+        if (msh == 10) RF_LAUNCH_ENC(false, 10); else if (msh < 0) RF_LAUNCH_ENC(false, -1); else RF_LAUNCH_ENC(false, 0);
     }
 #undef RF_LAUNCH_ENC
 #undef RF_LAUNCH_ENC_W

@@ -24,6 +24,8 @@ struct RansFastDev {
     u32 M;
     u32 enc_msh;    // encoder quotient shift MSH | pre-shift << 8 | r << 16 (rans_fast_build_tables);
                     // NUM_BITS_OUT = b > 1: (r + b) << 16 | b << 24 (rf_encode_entry_b)
+    u32 enc_folded; // 1: the pre-shift of a small table is folded into the reciprocals (rcp << pre), the quotient shift is 0:
+                    // the MSH_T = -1 flavour of the encoder (rf_encode_entry)
     u32 b;          // NUM_BITS_OUT: 1, or 4 / 8 / 16 on the same kernels since round 4
     u32 dec_sadd;   // b > 1: b - 1 - cbl, cbl = 32 - bit_width(L)   (rf_decode_symbol)
     u32 dec_notb;   // b > 1: ~(b - 1)
