@@ -109,10 +109,15 @@ int scl_rans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_fac
 void scl_rans_model_destroy(scl_rans_model *m);
 int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info);
 /* (ABI version 5) which encoder a batch of n_chunks aligned, equally long rows would run with the calling thread's
-   current settings: 'L' / 'S' = tuned NUM_BITS_OUT = 1 kernels with the 256-byte-ring / slot-ring writer (chosen by batch
-   size; SCL_RANS_ENC_WRITER=L|S in the environment forces one, read at every call), 'B' = tuned NUM_BITS_OUT > 1
-   kernels, 'G' = any-parameter kernels.  For tests and tools. */
+   current settings: 'L' / 'S' = the headline kernels (NUM_BITS_OUT = 1; NUM_BITS_OUT in {4, 8, 16} within their bounds)
+   with the 256-byte-ring / slot-ring writer (chosen by batch size; SCL_RANS_ENC_WRITER=L|S in the environment forces
+   one, read at every call), 'B' = the NUM_BITS_OUT > 1 kernels that serve what those bounds exclude (NUM_BITS_OUT = 2,
+   ...), 'G' = any-parameter kernels.  For tests and tools. */
 int scl_rans_encoder_kind(const scl_rans_model *m, uint64_t n_chunks);
+/* (ABI version 6) the encode and the decode kernel such a batch would run, as rocprofv3 prints them (template arguments
+   included for the tuned kernels), NUL-terminated into enc / dec (either may be NULL) of `cap` >= 96 bytes: what lets a
+   measurement name its kernels so that they can be matched against a kernel-trace summary.  No reference counterpart. */
+int scl_rans_kernel_names(const scl_rans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
 /* bytes a slot must have so that any block of n symbols fits (multiple of 128: whole cache lines, so the
    64-byte store bursts of the fast kernels never straddle a sector) */
 uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols);
@@ -147,6 +152,8 @@ int scl_tans_model_create(const uint32_t *h_freq, uint32_t K, uint64_t range_fac
 void scl_tans_model_destroy(scl_tans_model *m);
 int scl_tans_model_info(const scl_tans_model *m, scl_rans_info *info);
 uint64_t scl_tans_slot_bytes(const scl_tans_model *m, uint64_t n_symbols);
+/* (ABI version 6) as scl_rans_kernel_names (a tANS model the table-free rANS kernels can serve runs on them) */
+int scl_tans_kernel_names(const scl_tans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
 /* copy the device lookup tables back (for parity with tANS.py:285-337); any pointer may be NULL.
    h_enc / h_dec_sym / h_dec_xs have RANGE_FACTOR*M entries, h_nbits / h_thresh have K. */
 int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, uint32_t *h_nbits,

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "scl_device_count": (_int, [C.POINTER(_int)]),
     "scl_abi_version": (_int, []),
     "scl_rans_encoder_kind": (_int, [_vp, _u64]),
+    "scl_rans_kernel_names": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
+    "scl_tans_kernel_names": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
     "scl_set_any_parameter_kernels": (_int, [_int]),
     "scl_rans_model_create": (_int, [_u32p, _u32, _u64, _u32, _u32, C.POINTER(_vp)]),
     "scl_rans_model_destroy": (None, [_vp]),

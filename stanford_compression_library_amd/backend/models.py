@@ -117,12 +117,22 @@ class _DeviceModel:
         _lib.check(rc, f"scl_{self._prefix}_encode_host")
         return out[: (nbits.value + 7) // 8], int(nbits.value)
 
-    def decode_host(self, packed: np.ndarray, nbits: int, size_bits: int):
-        """(packed bytes, available bits) -> (index array of ``sym_dtype``, num_bits_consumed)."""
+    # decode_host sizes its host output from the stream's OWN size header: a damaged or hostile block can ask for up to
+    # 2^32 symbols (a symbol can cost 0 bits, so the stream length is no bound).  Callers cap it: above ``max_block_size``
+    # the call raises the AssertionError the size check in ``encode_block`` raises (drop-in classes: same exception type
+    # as the reference's ``assert data_block.size < (1 << DATA_BLOCK_SIZE_BITS)``), before anything is allocated.
+    DEFAULT_MAX_BLOCK_SIZE = 1 << 24
+
+    def decode_host(self, packed: np.ndarray, nbits: int, size_bits: int, max_block_size: Optional[int] = None):
+        """(packed bytes, available bits) -> (index array of ``sym_dtype``, num_bits_consumed).  ``max_block_size``
+        (default ``DEFAULT_MAX_BLOCK_SIZE`` = 2^24 symbols): largest block size the header may announce."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
+        cap = self.DEFAULT_MAX_BLOCK_SIZE if max_block_size is None else int(max_block_size)
+        assert int(n.value) <= cap, (f"encoded block announces {n.value} symbols, more than max_block_size = {cap} "
+                                     "(damaged stream? pass max_block_size to decode larger blocks)")
         out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
         rc = self._sym_fn("decode_host")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out), int(n.value),
@@ -150,8 +160,20 @@ class _DeviceModel:
             # ("rows", first row, rows of the whole shard): a shard of another shape starts over, so that a changing
             # shard shape cannot pile up one scratch per sub-batch start ever seen
             shard = stream_handle[2]
+            side = stream_handle[3] if len(stream_handle) > 3 else 0
             for k in [k for k in self._scratch_by_stream if isinstance(k, tuple) and k[2] != shard]:
-                del self._scratch_by_stream[k]
+                old = self._scratch_by_stream.pop(k)
+                # the evicted scratch was used on a side stream (raw handle in k[3] when the caller gave it): tell the
+                # caching allocator, so that the memory is not handed out again before that stream is done with it
+                old_side = k[3] if len(k) > 3 else 0
+                if old is not None and old_side:
+                    import torch
+
+                    old.record_stream(torch.cuda.ExternalStream(int(old_side), device=old.device))
+            if scratch is not None and side:
+                import torch
+
+                scratch.record_stream(torch.cuda.ExternalStream(int(side), device=scratch.device))
             self._scratch_by_stream[stream_handle] = scratch
             return
         self._scratch_by_stream[int(stream_handle or 0)] = scratch
@@ -217,7 +239,7 @@ class _DeviceModel:
         if self._needs_scratch:
             scratch, nbytes = self._scratch(b - a, sym.device)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
-            self._keep_scratch(("rows", a, n_rows), scratch)
+            self._keep_scratch(("rows", a, n_rows, int(stream_handle or 0)), scratch)
         with torch.cuda.device(sym.device):
             rc = self._fn("encode_batch")(*args, stream_handle)
         _lib.check(rc, f"scl_{self._prefix}_encode_batch")
@@ -354,12 +376,15 @@ class AecModel(_DeviceModel):
         return out[: (nbits.value + 7) // 8], int(nbits.value)
 
     def decode_host_resume(self, packed: np.ndarray, nbits: int, size_bits: int, counts: np.ndarray,
-                           past_k: np.ndarray):
+                           past_k: np.ndarray, max_block_size: Optional[int] = None):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         assert counts.dtype == np.uint32 and past_k.dtype == np.uint32 and counts.flags.c_contiguous
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
+        cap = self.DEFAULT_MAX_BLOCK_SIZE if max_block_size is None else int(max_block_size)
+        assert int(n.value) <= cap, (f"encoded block announces {n.value} symbols, more than max_block_size = {cap} "
+                                     "(damaged stream? pass max_block_size to decode larger blocks)")
         out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
         rc = self._sym_fn("decode_host_resume")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out),

@@ -116,7 +116,10 @@ class RcclGather:
         import torch
 
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        assert d_in.dtype == torch.int64 and d_out.dtype == torch.int64 and d_out.numel() == self.world * d_in.numel()
+        if d_in.dtype != torch.int64 or d_out.dtype != torch.int64 or d_out.numel() != self.world * d_in.numel():
+            # (not an assert: `python -O` strips those, and a wrong size here is a write past a device buffer)
+            raise ValueError(f"allgather_async: int64 tensors of n and world * n elements wanted, got {d_in.dtype} "
+                             f"[{d_in.numel()}] and {d_out.dtype} [{d_out.numel()}] for world = {self.world}")
         with torch.cuda.device(self.device):
             rc = self._L.scl_rccl_allgather_async(self._h, d_in.data_ptr(), d_out.data_ptr(), d_in.numel(), st.cuda_stream)
         self._check(rc, "scl_rccl_allgather_async")
@@ -132,7 +135,8 @@ class RcclGather:
         recv = (C.c_void_p * n)(*[p[3].data_ptr() if p[3] is not None else None for p in parts])
         nbytes = (C.c_uint64 * n)(*[int(p[1]) for p in parts])
         offs = np.ascontiguousarray(np.stack([np.asarray(p[2], dtype=np.uint64) for p in parts]))
-        assert offs.shape == (n, self.world + 1)
+        if offs.shape != (n, self.world + 1):
+            raise ValueError(f"gatherv: every part needs world + 1 = {self.world + 1} offsets, got an array of shape {offs.shape}")
         with torch.cuda.device(self.device):
             rc = self._L.scl_streams_gatherv_rccl(self._h, int(root), n, send, nbytes, recv,
                                                   offs.ctypes.data_as(C.POINTER(C.c_uint64)), st.cuda_stream)

@@ -93,9 +93,11 @@ class ArithmeticDecoder(_AecBase, DataDecoder):
         if self._stateful:
             counts, past = self.freq_model.export_state()
             idx, used = model.decode_host_resume(encoded_bitarray.packed(), len(encoded_bitarray),
-                                                 self.params.DATA_BLOCK_SIZE_BITS, counts, past)
+                                                 self.params.DATA_BLOCK_SIZE_BITS, counts, past,
+                                                 max_block_size=getattr(self, "max_block_size", None))
             self.freq_model.import_state(counts, past)
         else:
             idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
-                                          self.params.DATA_BLOCK_SIZE_BITS)
+                                          self.params.DATA_BLOCK_SIZE_BITS,
+                                          max_block_size=getattr(self, "max_block_size", None))
         return indices_to_block(idx, self._alphabet), used

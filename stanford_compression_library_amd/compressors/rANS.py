@@ -88,7 +88,8 @@ class rANSDecoder(BatchedStreamDecoderMixin, DataDecoder):
         model = self.params._device_model()
         try:
             idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
-                                          self.params.DATA_BLOCK_SIZE_BITS)
+                                          self.params.DATA_BLOCK_SIZE_BITS,
+                                          max_block_size=getattr(self, "max_block_size", None))
         except SclHipError as e:
             if e.code == E_CHUNK and "STATE" in e.message:
                 raise AssertionError("final rANS state != INITIAL_STATE") from e

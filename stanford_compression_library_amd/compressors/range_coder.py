@@ -72,5 +72,6 @@ class RangeDecoder(BatchedStreamDecoderMixin, _RangeBase, DataDecoder):
         """-> (DataBlock, num_bits_consumed incl. the size header) -- range_coder.py:269-317."""
         model = self._device_model()
         idx, used = model.decode_host(encoded_bitarray.packed(), len(encoded_bitarray),
-                                      self.params.DATA_BLOCK_SIZE_BITS)
+                                      self.params.DATA_BLOCK_SIZE_BITS,
+                                          max_block_size=getattr(self, "max_block_size", None))
         return indices_to_block(idx, self._alphabet), used

@@ -44,6 +44,12 @@ class DataEncoder(abc.ABC):
 
 
 class DataDecoder(abc.ABC):
+    # Largest block size a size header may announce to ``decode_block`` of the HIP-backed decoders before they allocate
+    # the output (None: the backend's default, 2^24 symbols).  A symbol can cost 0 bits, so the stream's length is no
+    # bound; a damaged header above this raises AssertionError -- the exception the encoder's own size check raises.
+    # No reference counterpart (the reference decodes symbol by symbol into a Python list).
+    max_block_size = None
+
     def reset(self):
         """Reset coder state, if any (no-op hook, reference :96-100)."""
 

@@ -236,11 +236,27 @@ __device__ __forceinline__ u32 af_state_shift_in(AfReader &rd, u32 state, u32 k,
     return ((u32)(both >> 32) & 0x7FFFFFFFu) | keep;
 }
 
-// minimum of v over the lanes of the wave that execute this (all of them must: call it outside divergent control flow)
+// minimum of v over the lanes of the wave that execute this.  The decode kernels call it after lanes have returned
+// (chunk >= n_chunks, a refused header): a butterfly would then read registers of disabled lanes -- ds_bpermute happens
+// to return 0 for those today, which made the count 0 and the caller fall back to its checked loop, but that is not a
+// contract, and a DPP lowering of the same shuffle would return garbage, i.e. an undersized minimum and unchecked reads
+// past a stream.  So: the butterfly only when all 64 lanes are here (the batch case); any other wave reads the live lanes'
+// values one by one through the scalar unit (v_readlane over the exec mask: ~6 scalar instructions per live lane, on a
+// path only partial waves and waves with a damaged chunk take) -- and still gets its unchecked stretches.
 __device__ __forceinline__ u32 af_wave_min(u32 v) {
+    u64 live = __builtin_amdgcn_ballot_w64(true);
+    if (live == ~0ull) {
 #pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) v = min(v, (u32)__shfl_xor((int)v, sft, 64));
-    return v;
+        for (int sft = 1; sft < 64; sft <<= 1) v = min(v, (u32)__shfl_xor((int)v, sft, 64));
+        return v;
+    }
+    u32 r = 0xFFFFFFFFu;
+    while (live) {
+        const int l = __builtin_ctzll(live);
+        r = min(r, (u32)__builtin_amdgcn_readlane((int)v, l));
+        live &= live - 1;
+    }
+    return r;
 }
 
 // ---- decoded symbols: four to a word, sixteen words to a 64-byte sector staged in LDS ([thread][64 bytes]), stored as four

@@ -15,7 +15,7 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 #define SCL_WAVE 64
-#define SCL_ABI_VERSION 5
+#define SCL_ABI_VERSION 6
 #define SCL_MAX_ALPHABET 65536u  // uint16 symbol indices (the *_u16 entry points); the uint8 entry points stop at 256
 
 // ---- host-side error plumbing ------------------------------------------------------------------
@@ -69,6 +69,7 @@ struct RowRelay {
     u8 *user_out = nullptr;  // decode side: where the rows go back to
     u64 user_stride = 0, stride = 0, n_rows = 0;
     u32 row_bytes = 0, sym_bytes = 1;
+    bool failed = false;  // the scratch could not be allocated: rows stay as they are (scl_last_error has the reason)
     // encode side: d_sym / sym_stride are replaced by an aligned copy when they are not aligned
     int in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks, hipStream_t stream);
     // decode side: d_out / out_stride are replaced by aligned scratch; out_end() copies the rows back

@@ -67,16 +67,23 @@ bool scl_force_generic(void) {
 }
 
 // dst[r * dst_stride + b] = src[r * src_stride + b] for b < row_bytes: four bytes per lane, no alignment assumed
-// (row_lens, when given: only the first min(row_lens[r], row_bytes) bytes of row r -- what a decoder really produced)
+// (row_lens, when given: only the first row_lens[r] bytes of row r -- what a decoder really produced.  A length ABOVE
+// row_bytes is a chunk the decoder refused (SCL_ST_CAPACITY: the tuned decoders store the header's n to out_lens before
+// they check it against out_cap, and decode nothing): nothing of such a row goes back -- the scratch behind it is
+// uninitialised pool memory)
 __global__ void __launch_bounds__(256) relay_rows_kernel(u8 *__restrict__ dst, u64 dst_stride, const u8 *__restrict__ src,
                                                         u64 src_stride, u32 row_bytes, u64 n_rows,
-                                                        const u32 *__restrict__ row_lens) {
+                                                        const u32 *__restrict__ row_lens, u32 sym_bytes) {
     const u32 quads = (row_bytes + 3) / 4;
     const u64 total = n_rows * quads;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += (u64)gridDim.x * 256) {
         const u64 r = i / quads;
         const u32 b = (u32)(i - r * quads) * 4;
-        const u32 len = row_lens ? min(row_lens[r], row_bytes) : row_bytes;
+        u32 len = row_bytes;
+        if (row_lens) {
+            len = row_lens[r] * sym_bytes;
+            if (row_lens[r] > row_bytes / sym_bytes) len = 0;  // refused chunk: see above
+        }
         if (b >= len) continue;
         const u8 *s = src + r * src_stride + b;
         u8 *d = dst + r * dst_stride + b;
@@ -86,13 +93,13 @@ __global__ void __launch_bounds__(256) relay_rows_kernel(u8 *__restrict__ dst, u
 }
 
 static int relay_launch(u8 *dst, u64 dst_stride, const u8 *src, u64 src_stride, u32 row_bytes, u64 n_rows, hipStream_t st,
-                        const u32 *row_lens = nullptr) {
+                        const u32 *row_lens = nullptr, u32 sym_bytes = 1) {
     if (!n_rows || !row_bytes) return SCL_OK;
     const u64 total = n_rows * ((row_bytes + 3) / 4);
     u64 blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(relay_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, dst, dst_stride, src, src_stride, row_bytes,
-                       n_rows, row_lens);
+                       n_rows, row_lens, sym_bytes);
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
 }
@@ -109,9 +116,14 @@ int RowRelay::in(const u8 *&d_sym, u64 &sym_stride, u32 chunk_len, u64 n_chunks,
     hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
     if (e != hipSuccess) {
         // no scratch, no re-laying: the caller's rows stay as they are, which sends the call to the any-parameter kernels
-        // (they take any alignment and need no scratch) instead of failing it
+        // (they take any alignment and need no scratch) instead of failing it.  The failure is RECORDED -- `failed`, and the
+        // text scl_last_error() returns -- so that a caller without such a fallback (a table-less tANS model) can report
+        // SCL_E_ALLOC instead of a misleading alignment message, and a silent ~100x slowdown can be explained.
         scratch = nullptr;
+        failed = true;
         (void)hipGetLastError();
+        scl_set_error("row relay: hipMallocAsync(%llu bytes) failed (%s): rows not re-laid, the any-parameter kernels serve "
+                      "this call", (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
         return SCL_OK;
     }
     if (int rc = relay_launch(scratch, stride, d_sym, sym_stride, chunk_len, n_chunks, st)) return rc;
@@ -127,7 +139,10 @@ int RowRelay::out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, 
     hipError_t e = hipMallocAsync((void **)&scratch, n_chunks * stride + 16, st);
     if (e != hipSuccess) {  // as above: the any-parameter kernels store to the caller's rows directly
         scratch = nullptr;
+        failed = true;
         (void)hipGetLastError();
+        scl_set_error("row relay: hipMallocAsync(%llu bytes) failed (%s): output rows not re-laid, the any-parameter kernels "
+                      "serve this call", (unsigned long long)(n_chunks * stride + 16), hipGetErrorString(e));
         return SCL_OK;
     }
     user_out = d_out;
@@ -143,7 +158,7 @@ int RowRelay::out_begin(u8 *&d_out, u64 &out_stride, u32 out_cap, u64 n_chunks, 
 // stale pool memory behind a row's symbols, the whole row of a chunk that failed -- never reaches the caller's buffer.
 int RowRelay::out_end(const u32 *d_out_lens) {
     if (!user_out) return SCL_OK;
-    return relay_launch(user_out, user_stride, scratch, stride, row_bytes * sym_bytes, n_rows, st, d_out_lens);
+    return relay_launch(user_out, user_stride, scratch, stride, row_bytes * sym_bytes, n_rows, st, d_out_lens, sym_bytes);
 }
 
 RowRelay::~RowRelay() {

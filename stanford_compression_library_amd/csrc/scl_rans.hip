@@ -261,14 +261,30 @@ extern "C" int scl_rans_model_info(const scl_rans_model *m, scl_rans_info *info)
 }
 
 // Which encoder a batch of n_chunks equally long, 16-byte aligned rows would run with the calling thread's current
-// settings: 'L' / 'S' = the NUM_BITS_OUT = 1 tuned kernels with the 256-byte-ring / slot-ring writer, 'B' = the tuned
-// kernels for NUM_BITS_OUT > 1, 'G' = the any-parameter kernels.  For tests and tools (which switch the writer with
+// settings: 'L' / 'S' = the headline kernels of scl_rans_fast.hip (NUM_BITS_OUT = 1, and since round 4 NUM_BITS_OUT in
+// {4, 8, 16} within their bounds) with the 256-byte-ring / slot-ring writer, 'B' = the kernels of scl_rans_fast_b.hip
+// (NUM_BITS_OUT = 2 and what those bounds exclude), 'G' = the any-parameter kernels.  For tests and tools (which switch the writer with
 // SCL_RANS_ENC_WRITER and want to know that the switch took).
 extern "C" int scl_rans_encoder_kind(const scl_rans_model *m, uint64_t n_chunks) {
     if (!m) return 0;
     if (scl_force_generic()) return 'G';
     if (m->fast) return rf_use_slot_writer(m, n_chunks) ? 'S' : 'L';
     return m->fastb ? 'B' : 'G';
+}
+
+// (ABI 6) the two kernels a batch of n_chunks aligned, equally long rows would run, named the way rocprofv3 prints them
+// (template arguments included for the tuned kernels; the any-parameter kernels by their function name) -- so that a
+// bench line's "kernel" fields can be matched mechanically against a committed kernel-trace summary.
+extern "C" int scl_rans_kernel_names(const scl_rans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap) {
+    SCL_REQUIRE(m && (enc || dec) && cap >= 96, "rans_kernel_names: null argument or a buffer below 96 bytes");
+    if (!scl_force_generic() && m->fast) {
+        rans_fast_kernel_names(m, n_chunks, enc, dec, (size_t)cap);
+        return SCL_OK;
+    }
+    const bool b = !scl_force_generic() && m->fastb;
+    if (enc) snprintf(enc, (size_t)cap, "%s", b ? "rans_encode_fastb_kernel" : "rans_encode_generic");
+    if (dec) snprintf(dec, (size_t)cap, "%s", b ? "rans_decode_fastb_kernel" : "rans_decode_generic");
+    return SCL_OK;
 }
 
 extern "C" uint64_t scl_rans_slot_bytes(const scl_rans_model *m, uint64_t n_symbols) {

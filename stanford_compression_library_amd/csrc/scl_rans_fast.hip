@@ -125,7 +125,8 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh
 // Entry {rcp, M - f, c, sh | (b k_lo) << 8}; msh_rt = . | . | (r + b) << 16 | b << 24.
 template <typename EncOut>
 __device__ __forceinline__ u32 rf_encode_entry_b(u32 &x, const EncEntry e, u32 msh_rt, EncOut &o) {  // returns bits released
-    const u32 q0 = rf_umulhi(x, e.rcp) >> e.k_lo;              // low five bits of the word = sh
+    const u32 q0 = rf_umulhi(x, e.rcp) >> (e.k_lo & 31u);      // low five bits of the word = sh (the mask costs nothing:
+                                                               // v_lshrrev_b32 reads five bits, the backend drops it)
     const u32 posb = (q0 >> ((msh_rt >> 16) & 0xFFu)) ? (msh_rt >> 24) : 0u;
     const u32 k = (e.k_lo >> 8) + posb;
     o.push(x, k);
@@ -778,79 +779,125 @@ bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks) {
     return 3 * rounds_s < 2 * rounds_l;
 }
 
+// What a batch of n_chunks runs: ONE place decides (the launch below switches on it, rans_fast_kernel_names prints it the
+// way rocprofv3 prints the instantiation -- bench.py's "kernel" fields come from there, so they can be matched
+// mechanically against profiles/*_kernel_trace_summary.txt).
+struct RfEncChoice {
+    bool slots;  // AnsBackWriterS (three workgroups per CU) instead of AnsBackWriterL
+    int check;   // CHECK_SYM: 0 = 256 symbols, 1 = K <= 128, 2 = 129..255
+    int msh;     // MSH_T: 10 = the literal (MSH, r) = (10, 16) form, -1 = pre-shift folded into the reciprocals, 0 = run time
+    int r;       // R_T (16 with msh = 10, else 0)
+    int nb;      // NB_T: 1 = NUM_BITS_OUT 1, 0 = NUM_BITS_OUT in {4, 8, 16}
+};
+static RfEncChoice rf_encode_choice(const scl_rans_model *m, u64 n_chunks) {
+    RfEncChoice c;
+    c.slots = rf_use_slot_writer(m, n_chunks);
+    c.check = m->fdev.K == 256 ? 0 : (m->fdev.K <= 128 ? 1 : 2);
+    if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}: run-time constants
+        c.msh = 0, c.r = 0, c.nb = 0;
+        return c;
+    }
+    // literal form: only without a pre-shift, and for the one (MSH, r) pair that is instantiated -- the reference
+    // defaults with a 4096-total table (m = 12, nsb = 29)
+    c.msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : (m->fdev.enc_folded ? -1 : 0);
+    c.r = c.msh > 0 ? 16 : 0;
+    c.nb = 1;
+    return c;
+}
+
 void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    // literal form: only without a pre-shift, and for the one (MSH, r) pair that is instantiated
-    const int msh = (m->fdev.enc_msh == (10u | (16u << 16))) ? 10 : (m->fdev.enc_folded ? -1 : 0);
-    const bool slots = rf_use_slot_writer(m, n_chunks);
-#define RF_LAUNCH_ENC_W(OUT, CHECK, MSH)                                                                             \
-    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, (MSH > 0 ? 16 : 0)>), dim3(blocks), dim3(RF_THREADS), 0, \
-                       st, m->fdev, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off,    \
-                       d_nbits, d_status)
-#define RF_LAUNCH_ENC(CHECK, MSH)                 \
-    do {                                          \
-        if (slots)                                \
-            RF_LAUNCH_ENC_W(EncOutS, CHECK, MSH); \
-        else                                      \
-            RF_LAUNCH_ENC_W(EncOutL, CHECK, MSH); \
-    } while (0)
-    if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}: run-time constants, the symbol check that fits the alphabet
-#define RF_LAUNCH_ENC_B(OUT, CHECK)                                                                                     \
-    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, 0, 0, 0>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
+    const RfEncChoice ch = rf_encode_choice(m, n_chunks);
+#define RF_LAUNCH_ENC_K(OUT, CHECK, MSH, R, NB)                                                                       \
+    hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, R, NB>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
                        d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
-        const int check = m->fdev.K == 256 ? 0 : (m->fdev.K <= 128 ? 1 : 2);
-        if (slots) {
-            if (check == 0) RF_LAUNCH_ENC_B(EncOutS, 0); else if (check == 1) RF_LAUNCH_ENC_B(EncOutS, 1); else RF_LAUNCH_ENC_B(EncOutS, 2);
-        } else {
-            if (check == 0) RF_LAUNCH_ENC_B(EncOutL, 0); else if (check == 1) RF_LAUNCH_ENC_B(EncOutL, 1); else RF_LAUNCH_ENC_B(EncOutL, 2);
-        }
-#undef RF_LAUNCH_ENC_B
-        return;
-    }
-    // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
-    if (m->fdev.K <= 128) {
-        if (msh == 10) RF_LAUNCH_ENC(1, 10); else if (msh < 0) RF_LAUNCH_ENC(1, -1); else RF_LAUNCH_ENC(1, 0);
-    } else if (m->fdev.K < 256) {
-        if (msh == 10) RF_LAUNCH_ENC(2, 10); else if (msh < 0) RF_LAUNCH_ENC(2, -1); else RF_LAUNCH_ENC(2, 0);
-    } else {
-        if (msh == 10) RF_LAUNCH_ENC(false, 10); else if (msh < 0) RF_LAUNCH_ENC(false, -1); else RF_LAUNCH_ENC(false, 0);
-    }
-#undef RF_LAUNCH_ENC
+#define RF_LAUNCH_ENC_W(CHECK, MSH, R, NB)                  \
+    do {                                                    \
+        if (ch.slots)                                       \
+            RF_LAUNCH_ENC_K(EncOutS, CHECK, MSH, R, NB);    \
+        else                                                \
+            RF_LAUNCH_ENC_K(EncOutL, CHECK, MSH, R, NB);    \
+    } while (0)
+#define RF_LAUNCH_ENC_C(MSH, R, NB)                         \
+    do {                                                    \
+        if (ch.check == 0)                                  \
+            RF_LAUNCH_ENC_W(0, MSH, R, NB);                 \
+        else if (ch.check == 1)                             \
+            RF_LAUNCH_ENC_W(1, MSH, R, NB);                 \
+        else                                                \
+            RF_LAUNCH_ENC_W(2, MSH, R, NB);                 \
+    } while (0)
+    if (ch.nb == 0)
+        RF_LAUNCH_ENC_C(0, 0, 0);
+    else if (ch.msh == 10)
+        RF_LAUNCH_ENC_C(10, 16, 1);
+    else if (ch.msh < 0)
+        RF_LAUNCH_ENC_C(-1, 0, 1);
+    else
+        RF_LAUNCH_ENC_C(0, 0, 1);
+#undef RF_LAUNCH_ENC_C
 #undef RF_LAUNCH_ENC_W
+#undef RF_LAUNCH_ENC_K
+}
+
+struct RfDecChoice {
+    int ml, cb, threads, nb;  // ML_T, CB_T, THREADS, NB_T of rans_decode_fast_kernel
+};
+static RfDecChoice rf_decode_choice(const scl_rans_model *m, u64 n_chunks) {
+    RfDecChoice c;
+    // up to 2 x 256 small workgroups are resident at once (64 KiB of LDS each): beyond that the 1024-lane form wins
+    c.threads = n_chunks > 2ull * 256 * RD_THREADS_SMALL ? RD_THREADS : RD_THREADS_SMALL;
+    c.nb = m->fdev.b != 1 ? 0 : 1;
+    if (m->fdev.b != 1)  // NUM_BITS_OUT in {4, 8, 16}
+        c.ml = 0, c.cb = 0;
+    else if (m->fdev.m_log2 == 0xFFFFFFFFu)  // total is not a power of two
+        c.ml = -1, c.cb = 0;
+    else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29)  // the reference defaults with a 4096-total table: literal constants
+        c.ml = 12, c.cb = 3;
+    else if (m->fdev.nsb <= 29)  // the state fits shifted left by three (rf_decode_symbol)
+        c.ml = 0, c.cb = 3;
+    else
+        c.ml = 0, c.cb = 0;
+    return c;
+}
+
+// the two kernels of a batch of n_chunks aligned, equally long rows, as rocprofv3 prints them
+void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap) {
+    const RfEncChoice e = rf_encode_choice(m, n_chunks);
+    const RfDecChoice d = rf_decode_choice(m, n_chunks);
+    if (enc)
+        snprintf(enc, cap, "rans_encode_fast_kernel<AnsBackWriter%c<256>, %d, %d, %d, %d>", e.slots ? 'S' : 'L', e.check, e.msh,
+                 e.r, e.nb);
+    if (dec) snprintf(dec, cap, "rans_decode_fast_kernel<%d, %d, %d, %d>", d.ml, d.cb, d.threads, d.nb);
 }
 
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
-#define RF_LAUNCH_DEC(ML, CB, TH)                                                                                  \
-    hipLaunchKernelGGL((rans_decode_fast_kernel<ML, CB, TH>), dim3((u32)((n_chunks + TH - 1) / TH)), dim3(TH), 0, st, \
+    const RfDecChoice ch = rf_decode_choice(m, n_chunks);
+#define RF_LAUNCH_DEC_K(ML, CB, TH, NB)                                                                               \
+    hipLaunchKernelGGL((rans_decode_fast_kernel<ML, CB, TH, NB>), dim3((u32)((n_chunks + TH - 1) / TH)), dim3(TH), 0, st, \
                        m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,   \
                        d_out_lens, d_consumed, d_status)
-    // up to 2 x 256 small workgroups are resident at once (64 KiB of LDS each): beyond that the 1024-lane form wins
-    const bool big = n_chunks > 2ull * 256 * RD_THREADS_SMALL;
-    if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}
-        if (big)
-            hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0, RD_THREADS, 0>), dim3((u32)((n_chunks + RD_THREADS - 1) / RD_THREADS)),
-                               dim3(RD_THREADS), 0, st, m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym,
-                               out_stride, out_cap, d_out_lens, d_consumed, d_status);
-        else
-            hipLaunchKernelGGL((rans_decode_fast_kernel<0, 0, RD_THREADS_SMALL, 0>),
-                               dim3((u32)((n_chunks + RD_THREADS_SMALL - 1) / RD_THREADS_SMALL)), dim3(RD_THREADS_SMALL), 0, st,
-                               m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
-                               d_out_lens, d_consumed, d_status);
-        return;
-    }
-    // the reference defaults with a 4096-total table (m = 12, nsb = 29) get literal constants
-    if (m->fdev.m_log2 == 0xFFFFFFFFu) {  // total is not a power of two
-        if (big) RF_LAUNCH_DEC(-1, 0, RD_THREADS); else RF_LAUNCH_DEC(-1, 0, RD_THREADS_SMALL);
-    } else if (m->fdev.m_log2 == 12 && m->fdev.nsb == 29) {
-        if (big) RF_LAUNCH_DEC(12, 3, RD_THREADS); else RF_LAUNCH_DEC(12, 3, RD_THREADS_SMALL);
-    } else if (m->fdev.nsb <= 29) {  // the state fits shifted left by three (rf_decode_symbol)
-        if (big) RF_LAUNCH_DEC(0, 3, RD_THREADS); else RF_LAUNCH_DEC(0, 3, RD_THREADS_SMALL);
-    } else {
-        if (big) RF_LAUNCH_DEC(0, 0, RD_THREADS); else RF_LAUNCH_DEC(0, 0, RD_THREADS_SMALL);
-    }
+#define RF_LAUNCH_DEC(ML, CB, NB)                           \
+    do {                                                    \
+        if (ch.threads == RD_THREADS)                       \
+            RF_LAUNCH_DEC_K(ML, CB, RD_THREADS, NB);        \
+        else                                                \
+            RF_LAUNCH_DEC_K(ML, CB, RD_THREADS_SMALL, NB);  \
+    } while (0)
+    if (ch.nb == 0)
+        RF_LAUNCH_DEC(0, 0, 0);
+    else if (ch.ml < 0)
+        RF_LAUNCH_DEC(-1, 0, 1);
+    else if (ch.ml == 12)
+        RF_LAUNCH_DEC(12, 3, 1);
+    else if (ch.cb == 3)
+        RF_LAUNCH_DEC(0, 3, 1);
+    else
+        RF_LAUNCH_DEC(0, 0, 1);
 #undef RF_LAUNCH_DEC
+#undef RF_LAUNCH_DEC_K
 }

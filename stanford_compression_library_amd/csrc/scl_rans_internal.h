@@ -71,6 +71,7 @@ struct scl_rans_model {
 // scl_rans_fast.hip
 int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum);
 bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks);
+void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap);
 void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
                              u32 *d_status, hipStream_t st);

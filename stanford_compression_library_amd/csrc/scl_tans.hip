@@ -368,6 +368,22 @@ extern "C" int scl_tans_model_tables(const scl_tans_model *m, uint32_t *h_enc, u
     return SCL_OK;
 }
 
+// (ABI 6) as scl_rans_kernel_names: a tANS model the table-free rANS kernels can serve runs on them (same stream) unless
+// SCL_TANS_KERNELS=table is set
+extern "C" int scl_tans_kernel_names(const scl_tans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap) {
+    SCL_REQUIRE(m && (enc || dec) && cap >= 96, "tans_kernel_names: null argument or a buffer below 96 bytes");
+    const bool tuned = !scl_force_generic();
+    const bool table_first = m->fast && tans_table_kernels_forced();
+    if ((tuned || !m->tables) && m->rans && !(table_first && tuned)) {
+        rans_fast_kernel_names(m->rans, n_chunks, enc, dec, (size_t)cap);
+        return SCL_OK;
+    }
+    const bool f = tuned && m->fast;
+    if (enc) snprintf(enc, (size_t)cap, "%s", f ? "tans_encode_fast_kernel" : "tans_encode_kernel");
+    if (dec) snprintf(dec, (size_t)cap, "%s", f ? "tans_decode_fast_kernel" : "tans_decode_kernel");
+    return SCL_OK;
+}
+
 extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
                                      const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks, uint8_t *d_out,
                                      uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,
@@ -400,6 +416,11 @@ extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_s
                                 d_out_nbits, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return SCL_OK;
+    }
+    if (!m->tables && relay.failed) {  // the rows WERE the problem, and the scratch to re-lay them could not be had
+        scl_set_error("tans_encode_batch: out of device memory re-laying unaligned symbol rows (hipMallocAsync failed) and "
+                      "this model has no lookup tables for the any-parameter kernels");
+        return SCL_E_ALLOC;
     }
     SCL_REQUIRE(m->tables, "tans_encode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned symbol rows and slots of scl_tans_slot_bytes");
@@ -443,6 +464,11 @@ extern "C" int scl_tans_decode_batch(const scl_tans_model *m, const uint8_t *d_i
                                 out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
         SCL_HIP_TRY(hipGetLastError());
         return relay.out_end(d_out_lens);
+    }
+    if (!m->tables && relay.failed) {
+        scl_set_error("tans_decode_batch: out of device memory re-laying unaligned output rows (hipMallocAsync failed) and "
+                      "this model has no lookup tables for the any-parameter kernels");
+        return SCL_E_ALLOC;
     }
     SCL_REQUIRE(m->tables, "tans_decode_batch: this model has no lookup tables (RANGE_FACTOR*M > 2^26); it needs "
                            "16-byte aligned buffers");

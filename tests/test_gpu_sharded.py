@@ -59,6 +59,52 @@ def test_rccl_transport_one_rank():
         comm.close()
 
 
+def test_config5_one_rank_leg_at_full_size():
+    """BASELINE.json configs[4], the part one GPU can run AT ITS SIZE (S5 of SURVEY 8d: rank 0's shard = 1024 blocks of
+    1 MiB = 262 144 chunks of 4 KiB, seed 5000): per-GPU rANS encode, compaction, the RCCL exchange through the C ABI
+    (one-rank communicator) -- size-independent properties: the gathered payload is the compaction byte for byte, the
+    per-block offset table has 1024 + 1 increasing entries ending at the total, every chunk decodes back from the
+    GATHERED buffer (decoder reading dense streams by their gathered offsets), consumed == produced, and a fixed sample
+    of chunks equals the oracle bit for bit."""
+    import scl_oracle as orc
+    from stanford_compression_library_amd import bench_data
+    from stanford_compression_library_amd.backend import lib, models
+    from stanford_compression_library_amd.backend.sharded import RcclGather, block_offsets, gather_streams_to_root
+
+    lib.require_device()
+    dev = torch.device("cuda:0")
+    freq = bench_data.t256_table()
+    model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+    n_chunks, chunk_len = 262144, 4096
+    sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000, device=dev)
+    enc = model.encode_batch(sym)
+    dense, offs = models.compact(enc)
+    total = int(offs[-1])
+    comm = RcclGather(1, 0, dev)
+    try:
+        assert comm.nranks == 1
+        got_total, out, goffs = gather_streams_to_root(dense, offs, 1, 0, dev, return_data=True, comm=comm)
+    finally:
+        comm.close()
+    torch.cuda.synchronize()
+    assert got_total == total and torch.equal(goffs, offs) and torch.equal(out[:total], dense[:total])
+    blocks = block_offsets(goffs, 256)  # 1 MiB blocks
+    assert blocks.numel() == 1025 and int(blocks[0]) == 0 and int(blocks[-1]) == total
+    assert bool((blocks[1:] > blocks[:-1]).all())
+    # decode from the gathered buffer: stream c = the nbits[c] bits from byte goffs[c] on (DENSE records are left-aligned)
+    buf = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+    buf[:total] = out[:total]
+    dec, dlens, used, status = model.decode_batch(buf, goffs[:-1] * 8, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0 and torch.equal(dec, sym) and torch.equal(used, enc.nbits)
+    assert int(dlens.min()) == chunk_len == int(dlens.max())
+    g_np, o_np, nb = out.cpu().numpy(), goffs.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in (0, 1, 255, 256, 4095, 131072, n_chunks - 1):
+        rb, rn = orc.rans_encode(sym[c].cpu().numpy(), freq)
+        assert int(nb[c]) == rn and int(o_np[c + 1] - o_np[c]) == (rn + 7) // 8
+        assert np.array_equal(g_np[o_np[c]:o_np[c + 1]], rb[:(rn + 7) // 8]), f"chunk {c}: gathered bytes != oracle"
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, {root!r})
@@ -115,7 +161,7 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def _run_two_ranks(tmp_path, rccl):
+def _run_ranks(tmp_path, world, rccl):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -123,27 +169,39 @@ def _run_two_ranks(tmp_path, rccl):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, rccl=rccl))
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    outs = []
+    try:
+        for p_ in procs:
+            outs.append(p_.communicate(timeout=900)[0])
+    finally:
+        for p_ in procs:  # a rank that failed leaves its peers waiting in a collective: never leave them behind
+            if p_.poll() is None:
+                p_.kill()
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(o[-1500:] for o in outs)
     assert "SHARDED_GPU_OK" in outs[0]
 
 
-def test_two_ranks_share_the_gpu_gloo(tmp_path):
-    _run_two_ranks(tmp_path, rccl=False)
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_share_the_gpu_gloo(tmp_path, world):
+    """the N-rank code path (block-contiguous shards, per-rank encode + compaction on the HIP kernels, the root's global
+    offset table, the overlapped pipeline) at world sizes 2 and 8 -- configs[4]'s rank count -- on ONE device over gloo"""
+    _run_ranks(tmp_path, world, rccl=False)
 
 
-def test_two_ranks_two_gpus_rccl(tmp_path):
-    """the real thing, whenever the box has two devices: two ranks on cuda:0 / cuda:1, torch's RCCL process group plus
-    the C ABI's own communicator; ncclAllGather / grouped ncclSend / ncclRecv meet a peer; the plain gather and the
-    overlapped pipeline are compared chunk by chunk with a one-process run.  Also covers model handles created on a
-    device other than 0."""
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two HIP devices (the gpurun pool hands out one-GPU boxes)")
-    _run_two_ranks(tmp_path, rccl=True)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_on_their_own_gpus_rccl(tmp_path, world):
+    """the real thing, at every world size the box has devices for: ranks on cuda:0 .. cuda:world-1, torch's RCCL process
+    group plus the C ABI's own communicator; ncclAllGather / grouped ncclSend / ncclRecv meet peers; the plain gather and
+    the overlapped pipeline are compared chunk by chunk with a one-process run.  Also covers model handles created on a
+    device other than 0.  Skips cleanly on the one-GPU boxes of the gpurun pool, so that the first multi-GPU lease
+    validates the exchange by itself."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} HIP devices, this box has {torch.cuda.device_count()}")
+    _run_ranks(tmp_path, world, rccl=True)
 
 
 def test_model_records_its_device():

@@ -134,10 +134,11 @@ def test_histogram_u16_equals_get_counts(K):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N > 1 code path (per-rank shards and seeds, barriers, max-over-ranks timing, rank-0 JSON line) run as
-    two torch.distributed ranks that share cuda:0 and talk over gloo (SCL_BENCH_SHARED_GPU=1; RCCL refuses two ranks on
-    one device, and the GPU box has one)."""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_two_ranks_on_one_gpu(ranks):
+    """bench.py's N > 1 code path (per-rank shards and seeds, barriers, max-over-ranks timing, rank-0 JSON line, the
+    self-validating --gather) run as 2 and as 8 torch.distributed ranks that share cuda:0 and talk over gloo
+    (SCL_BENCH_SHARED_GPU=1; RCCL refuses two ranks on one device, and the GPU box has one)."""
     import json
     import os
     import socket
@@ -149,20 +150,23 @@ def test_bench_two_ranks_on_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SCL_BENCH_SHARED_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--chunks", "4096", "--no-cpu-baseline", "--gather"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2",
+           "--warmup", "1", "--min-warm-ms", "0", "--chunks", "4096", "--no-cpu-baseline", "--gather"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]  # rank 0 only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
+    assert out["n_gpus"] == ranks and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
     assert out["value"] > 0 and out["config"]["chunks_per_gpu"] == 4096
     assert out["value_definition"] == "slots" and 0 < out["value_dense"] < out["value"]
+    assert out["multi_gpu"]["ranks"] == ranks and out["multi_gpu"]["scaling_efficiency"] > 0
     g = out["gather"]  # configs[4]: encode -> compact -> gather, sequential and as a pipeline of sub-batches
-    assert g["gathered_bytes"] > 2 * 4096 * 3000 and g["blocks_1MiB"] == 2 * 4096 // 256
+    assert g["gathered_bytes"] > ranks * 4096 * 3000 and g["blocks_1MiB"] == ranks * 4096 // 256
     assert all(g[k] > 0 for k in ("encode_ms", "compact_ms", "gather_ms", "sequential_ms", "overlapped_ms"))
+    assert g["verified"].startswith("per-rank size")  # the root checked what it received against the ranks' checksums
+    assert list(out)[-1] == "summary" and len(json.dumps(out["summary"])) <= 1024
 
 
 @pytest.mark.gpu

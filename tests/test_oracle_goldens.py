@@ -140,8 +140,6 @@ def test_restatement_rans(case):
     from stanford_compression_library_amd.core.prob_dist import Frequencies
     from stanford_compression_library_amd.utils.bitarray_utils import BitArray
 
-    if case.n > 1100:
-        pytest.skip("per-symbol Python with quadratic prepends: the long vectors stay with the C oracle")
     p = rst.RansSetup(Frequencies(dict(enumerate(case.freq))), case.size_bits, case.b, case.RF)
     bits = rst.rans_encode_block(p, case.arr("sym").tolist())
     assert len(bits) == case.nbits and np.array_equal(bits.packed(), case.arr("out"))
@@ -151,8 +149,8 @@ def test_restatement_rans(case):
 
 
 def _small(case, limit):
-    if case.n > limit:
-        pytest.skip("per-symbol Python: the long vectors stay with the C oracle")
+    """(until round 5 vectors longer than `limit` were skipped here as too slow for per-symbol Python; measured, the
+    longest of them takes a few seconds, so every golden pins the restatement now -- VERDICT r4 "missing" #5)"""
 
 
 @pytest.mark.parametrize("case", TANS, ids=golden_ids(TANS))

@@ -19,19 +19,21 @@ def entry(pmc_path, bench_path, out_path):
     vals = {}
     for line in open(pmc_path):
         m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch=([0-9.e+]+)", line)
-        if m and "cp_" not in m.group(1):
-            side = "encode" if "encode" in m.group(1) else "decode" if "decode" in m.group(1) else None
+        if m:
+            # cp_copy = the compaction pass of roofline_dense (the three scan kernels next to it move < 0.5 % of its bytes)
+            side = ("compact" if "cp_copy" in m.group(1) else None if "cp_" in m.group(1) else
+                    "encode" if "encode" in m.group(1) else "decode" if "decode" in m.group(1) else None)
             if side:
                 vals.setdefault(side, {"kernel": m.group(1).strip()})[m.group(2)] = float(m.group(3))
     in_bytes = b["config"]["chunks_per_gpu"] * b["config"]["chunk_len"]
     stream_bytes = b["roofline_encode"]["algorithmic_bytes_per_launch"] - in_bytes
     # csrc_sha: the kernel sources the pass was taken on (bench.py csrc_sha()); bench.py quotes an entry only for the same
-    out = {"key": b["traffic_key"], "csrc_sha": b.get("csrc_sha"),
+    out = {"key": b["traffic_key"], "csrc_sha": b.get("csrc_sha"), "core_sha": b.get("core_sha"),
            "algorithmic_bytes_per_launch": b["roofline_encode"]["algorithmic_bytes_per_launch"]}
     for side, v in vals.items():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
-        must_read = in_bytes if side == "encode" else stream_bytes
+        must_read = in_bytes if side == "encode" else stream_bytes  # (compact: the streams, out of their slots)
         raw = v["FETCH_SIZE"] * 1024
         mult = 2 if raw < 0.75 * must_read else 1
         out[side] = int(raw * mult + v["WRITE_SIZE"] * 1024)
