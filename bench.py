@@ -659,12 +659,11 @@ def summary_entry(r_enc, r_dec, r_dense, cpu, rst):
     def f3(x):
         return None if x is None else round(x, 3)
 
-    return {"enc_ms": f3(r_enc["avg_launch_ms"]), "dec_ms": f3(r_dec["avg_launch_ms"]), "dec_dd_ms": f3(r_dec.get("after_decode_ms")),
+    return {"enc": f3(r_enc["avg_launch_ms"]), "dec": f3(r_dec["avg_launch_ms"]), "dec_dd": f3(r_dec.get("after_decode_ms")),
             "f_enc": f3(r_enc["frac"]), "f_dec": f3(r_dec["frac"]), "f_dense": f3(r_dense["frac"]) if r_dense else None,
-            "dense_ms": f3(min(r_dense["sequential_ms"], r_dense["pipelined_ms"] or 1e9)) if r_dense else None,
             "tx": [r_enc.get("traffic_over_algorithmic"), r_dec.get("traffic_over_algorithmic"),
                    r_dense.get("traffic_over_algorithmic") if r_dense else None],
-            "cpu_c": cpu["value"] if cpu else None, "cpu_py": rst["value"] if rst else None}
+            "cpu_c": round(cpu["value"], 1) if cpu else None, "cpu_py": round(rst["value"], 3) if rst else None}
 
 
 def other_workloads(args):
@@ -903,9 +902,10 @@ def main():
         if others:
             out["other_configs"] = others
         # LAST key, <= 1 KB: the driver's record keeps the tail of the line.  One entry per configuration -- kernel times
-        # (ms; dec_dd = the decode kernel behind another decode instead of behind the encode), fractions of the 8 TB/s
-        # roofline on algorithmic bytes (f_dense: encode + compaction), tx = PMC HBM traffic over algorithmic bytes
-        # [encode, decode, dense] where a stamped pass exists, cpu_c / cpu_py = C port / pure-Python restatement, MB/s.
+        # (enc, dec: ms per launch; dec_dd = the decode kernel behind another decode instead of behind the encode), fractions
+        # of the 8 TB/s roofline on algorithmic bytes (f_dense: encode + compaction), tx = PMC HBM traffic over algorithmic
+        # bytes [encode, decode, dense] where a stamped pass exists, cpu_c / cpu_py = C port / pure-Python restatement (MB/s),
+        # MBps = the configuration's round-trip value.
         summ = {"headline": summary_entry(r_enc, r_dec, r_dense, res.get("cpu_baseline"), res.get("cpu_baseline_restatement"))}
         summ["headline"]["MBps"] = round(value)
         for o in others:

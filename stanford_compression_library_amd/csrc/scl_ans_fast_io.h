@@ -291,7 +291,12 @@ struct AnsBackWriterL {
             const char *r = lds + qbase + R * LANE_BYTES;
             const uint4 q0 = *reinterpret_cast<const uint4 *>(r + (l0 & 255u));
             const uint4 q1 = *reinterpret_cast<const uint4 *>(r + ((l0 + 64u) & 255u));
+#if RF_ABLATE & 4  // timing experiment 4: every line is stored over the slot's last line (same instructions, writes merge in L2)
+            u8 *p = wg_out + (scl_quad_bcast<R>(goff0) - 128u + j16);
+            (void)go_s;
+#else
             u8 *p = wg_out + (go_s - 128u + j16);
+#endif
 #if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
@@ -565,6 +570,9 @@ struct CoopLineStore {
     // a[b] = bytes [16 b, 16 b + 16) of this lane's line, which starts at byte `pos` of its row
     __device__ __forceinline__ void store(uint4 *a, u32 pos) const {
         scl_transpose8(a);
+#if RD_ABLATE & 4  // timing experiment: every line is stored over the row's first line (same instruction stream, the writes merge in L2)
+        pos = 0;
+#endif
 #pragma unroll
         // non-temporal: a decoded line is written once, whole, and never read here.  (With per-lane 16-byte pieces the
         // same hint was a disaster -- they then reach memory unmerged; with whole lines it leaves decode unchanged and
@@ -574,6 +582,8 @@ struct CoopLineStore {
             const u32x4_nt t = {a[j].x, a[j].y, a[j].z, a[j].w};
 #if RD_ABLATE & 1  // timing experiment: no global stores
             asm volatile("" : : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+#elif defined(RD_PLAIN_STORE)  // timing experiment: ordinary stores (acknowledged by L2, written back later)
+            *reinterpret_cast<u32x4_nt *>(base + (u64)(8 * j) * stride + pos) = t;
 #else
             __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(base + (u64)(8 * j) * stride + pos));
 #endif
