@@ -289,6 +289,18 @@ int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, co
                            uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
                            uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch, void *stream);
 
+/* (ABI version 7) Host-side index of a framed block file held in host memory -- the walk EncodedBlockReader.get_block makes
+   one record at a time (encoded_stream.py:196-225) followed by Padder.remove_byte_padding (:48-58), for a whole buffer:
+   for every COMPLETE record [u32 BE payload bytes][payload] starting at h_buf[0] writes where its stream starts (bit offset
+   from h_buf), its number of stream bits and the value of its first size_bits bits (the block's DATA_BLOCK_SIZE_BITS
+   header; size_bits <= 64).  Stops in front of the first record that crosses buf_size or after max_records; *n_records
+   = records indexed, *consumed = bytes they span (what is left belongs to the next buffer -- or is a truncated file).
+   No device, no stream.  SCL_E_PARAM (with *n_records / *consumed = what came before) for a record with an empty payload
+   or one shorter than its padding and size header. */
+int scl_framed_index_host(const uint8_t *h_buf, uint64_t buf_size, uint32_t size_bits, uint64_t max_records,
+                          uint64_t *h_bit_offset, uint64_t *h_nbits, uint64_t *h_block_size,
+                          uint64_t *n_records, uint64_t *consumed);
+
 /* ---- multi-GPU: variable-length gather of compacted streams over RCCL (SURVEY.md 8e, configs[4]) ------
  * No reference counterpart (the reference has no communication).  One process per GPU; every rank encodes and
  * compacts its own block-contiguous shard, then the dense payloads go to one rank: an all-gather of the byte

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "scl_streams_compact": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp]),
     "scl_streams_compact_at": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp, _vp]),
     "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),
+    "scl_framed_index_host": (_int, [_vp, _u64, _u32, _u64, _vp, _vp, _vp, _u64p, _u64p]),
     "scl_histogram_u8": (_int, [_vp, _u64, _vp, _vp]),
     "scl_histogram_u16": (_int, [_vp, _u64, _u32, _vp, _vp, _vp]),
     "scl_rccl_inject_api": (_int, [_vp]),

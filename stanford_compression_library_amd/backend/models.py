@@ -520,6 +520,29 @@ def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     return out, offsets
 
 
+def framed_index_host(buf: np.ndarray, size_bits: int, max_records: Optional[int] = None):
+    """Index of a framed block file held in host memory (``scl_framed_index_host``: the walk
+    ``EncodedBlockReader.get_block`` + ``Padder.remove_byte_padding`` make one record at a time, encoded_stream.py:196-225,
+    :48-58) -> (bit_offset uint64[n], nbits uint64[n], block_size uint64[n], consumed_bytes).  ``buf`` is a contiguous
+    uint8 array; records that cross its end are left for the caller (``consumed_bytes`` says where they start).  A
+    malformed record raises ``AssertionError`` -- the exception the reference's reader asserts with."""
+    assert buf.dtype == np.uint8 and buf.ndim == 1 and buf.flags.c_contiguous
+    L = _lib.load()
+    # a record is at least 5 bytes (4-byte size + one payload byte)
+    cap = int(buf.size // 5 + 1 if max_records is None else max_records)
+    offs = np.empty(cap, dtype=np.uint64)
+    nbits = np.empty(cap, dtype=np.uint64)
+    sizes = np.empty(cap, dtype=np.uint64)
+    n, used = C.c_uint64(0), C.c_uint64(0)
+    rc = L.scl_framed_index_host(buf.ctypes.data if buf.size else None, buf.size, int(size_bits), cap,
+                                 offs.ctypes.data, nbits.ctypes.data, sizes.ctypes.data, C.byref(n), C.byref(used))
+    if rc == _lib.E_PARAM:
+        raise AssertionError(_lib.last_error())
+    _lib.check(rc, "scl_framed_index_host")
+    k = int(n.value)
+    return offs[:k], nbits[:k], sizes[:k], int(used.value)
+
+
 class DensePipeline:
     """Encode a batch straight to DENSE streams (every chunk's ``BitArray.tobytes()`` back to back + int64 offsets[n + 1],
     or the reference's framed file bytes) in sub-batches on two streams: the compaction of sub-batch i runs while sub-batch

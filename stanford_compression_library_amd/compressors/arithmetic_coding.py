@@ -8,7 +8,8 @@ Like the reference, an encoder / decoder object OWNS its ``freq_model`` and neve
 model object is in -- counts and, for order-k, the last k symbols -- and leaves the advanced state in it, so
 block 2+ of ``encode()`` / ``encode_file()`` is bit-identical to the reference's as well
 (``scl_aec_{encode,decode}_host_resume``; fixture ``tests/golden/golden_stream.npz``).  The batched device API
-(``backend.models.AecModel.encode_batch``) keeps the other meaning: one chunk = one fresh coder.
+(``backend.models.AecModel.encode_batch``) keeps the other meaning: one chunk = one fresh coder -- which is what a
+``FixedFreqModel`` stream is, so ``encode()`` / ``decode()`` of a static model run as batched launches (round 5).
 """
 from __future__ import annotations
 
@@ -20,6 +21,7 @@ from ..core.data_block import DataBlock
 from ..core.data_encoder_decoder import DataDecoder, DataEncoder
 from ..utils.bitarray_utils import BitArray
 from ._common import check_alphabet, indices_to_block, symbols_to_indices
+from ._stream_batch import BatchedStreamDecoderMixin, BatchedStreamEncoderMixin
 from .probability_models import KIND_FIXED, FreqModelBase
 
 __all__ = ["AECParams", "ArithmeticEncoder", "ArithmeticDecoder"]
@@ -61,7 +63,18 @@ class _AecBase:
         return self._model
 
 
-class ArithmeticEncoder(_AecBase, DataEncoder):
+class ArithmeticEncoder(BatchedStreamEncoderMixin, _AecBase, DataEncoder):
+    def _batch_model(self):
+        return self._device_model(), self._index_of
+
+    def encode(self, data_stream, block_size: int, encode_writer):
+        """A FixedFreqModel makes the blocks independent: one batched launch per slab (compressors/_stream_batch.py).  An
+        adaptive model carries its state from block to block (quirk Q4): the reference's block loop, one block at a time."""
+        self._device_model()
+        if self._stateful:
+            return DataEncoder.encode(self, data_stream, block_size, encode_writer)
+        return super().encode(data_stream, block_size, encode_writer)
+
     def encode_block(self, data_block: DataBlock) -> BitArray:
         """[size | renormalisation bits | termination bits] -- arithmetic_coding.py:80-161.
         The reference's ``size < 1 << MAX_BLOCK_SIZE`` assert (a 2^32-bit integer, quirk Q3) is replaced by
@@ -86,7 +99,18 @@ class ArithmeticEncoder(_AecBase, DataEncoder):
         return BitArray.from_packed(packed, nbits)
 
 
-class ArithmeticDecoder(_AecBase, DataDecoder):
+class ArithmeticDecoder(BatchedStreamDecoderMixin, _AecBase, DataDecoder):
+    def _batch_model(self):
+        self._size_bits = self.params.DATA_BLOCK_SIZE_BITS
+        return self._device_model(), self._alphabet
+
+    def decode(self, encode_reader, output_stream):
+        """batched for a FixedFreqModel, the block loop for adaptive models (see ``ArithmeticEncoder.encode``)"""
+        self._device_model()
+        if self._stateful:
+            return DataDecoder.decode(self, encode_reader, output_stream)
+        return super().decode(encode_reader, output_stream)
+
     def decode_block(self, encoded_bitarray: BitArray) -> Tuple[DataBlock, int]:
         """-> (DataBlock, num_bits_consumed); trailing bits are tolerated -- arithmetic_coding.py:203-287."""
         model = self._device_model()

@@ -4,10 +4,18 @@ Same classes and methods as reference scl/core/data_stream.py (``DataStream`` :1
 :104-160, ``FileDataStream`` :163-213, ``TextFileDataStream`` :216-235, ``Uint8FileDataStream`` :238-258).  The
 reference pulls one symbol per ``file.read(1)``; here ``get_block`` / ``write_block`` move whole blocks in one
 read / write, which is what lets a stream feed a batched encode.
+
+Bulk extension (no reference counterpart; used by compressors/_stream_batch.py when a stream offers it): the file streams
+also move symbols as numpy arrays of integer CODES -- ``read_codes(n)`` -> up to n symbols (``None`` at the end),
+``write_codes(array)``, ``symbol_of(code)`` (what ``get_symbol`` returns for it) / ``code_of(symbol)`` (what ``write_symbol``
+writes for it) -- a byte is its own code, a
+character its code point.  A stream of the batched coders then never builds a Python list of symbols.
 """
 from __future__ import annotations
 
 import abc
+
+import numpy as np
 
 from .data_block import DataBlock
 
@@ -115,6 +123,32 @@ class TextFileDataStream(FileDataStream):
     def write_block(self, data_block: DataBlock):
         self.file_obj.write("".join(data_block.data_list))
 
+    # -- bulk extension: characters as code points ------------------------------------------------------
+    @staticmethod
+    def code_of(symbol):
+        """the code point ``write_symbol`` writes for an alphabet symbol, or None when it is not one character"""
+        return ord(symbol) if isinstance(symbol, str) and len(symbol) == 1 else None
+
+    @staticmethod
+    def symbol_of(code: int):
+        return chr(code)
+
+    def read_codes(self, n: int):
+        """the next up to n characters as code points: uint8 when they all fit a byte, else uint32"""
+        text = self.file_obj.read(n)
+        if not text:
+            return None
+        try:
+            return np.frombuffer(text.encode("latin-1"), dtype=np.uint8)
+        except UnicodeEncodeError:
+            return np.frombuffer(text.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+
+    def write_codes(self, codes: np.ndarray):
+        if codes.dtype == np.uint8:
+            self.file_obj.write(codes.tobytes().decode("latin-1"))
+        else:
+            self.file_obj.write(codes.astype("<u4").tobytes().decode("utf-32-le", "surrogatepass"))
+
 
 class Uint8FileDataStream(FileDataStream):
     """bytes of a binary file as ints 0..255 (open with "rb" / "wb")"""
@@ -133,3 +167,28 @@ class Uint8FileDataStream(FileDataStream):
 
     def write_block(self, data_block: DataBlock):
         self.file_obj.write(bytes(data_block.data_list))
+
+    # -- bulk extension: a byte is its own code -----------------------------------------------------------
+    @staticmethod
+    def code_of(symbol):
+        """the byte ``write_symbol`` writes for an alphabet symbol, or None when it cannot write it"""
+        if isinstance(symbol, (int, np.integer)) and 0 <= int(symbol) <= 255:
+            return int(symbol)
+        return None
+
+    @staticmethod
+    def symbol_of(code: int):
+        return int(code)
+
+    def read_codes(self, n: int, out: np.ndarray = None):
+        """the next up to n bytes as a uint8 array (read straight into ``out`` -- e.g. a pinned staging buffer -- when
+        given); None at the end of the file"""
+        if out is not None:
+            got = self.file_obj.readinto(memoryview(out)[:n])
+            return out[:got] if got else None
+        raw = self.file_obj.read(n)
+        return np.frombuffer(raw, dtype=np.uint8) if raw else None
+
+    def write_codes(self, codes: np.ndarray):
+        assert codes.dtype == np.uint8
+        self.file_obj.write(memoryview(np.ascontiguousarray(codes)))

@@ -160,6 +160,18 @@ struct AnsBackWriter {
     }
 };
 
+// timing experiments (off in the product): non-temporal hints on whole-line accesses
+typedef u32 scl_u32x4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 scl_load16_nt(const uint4 *p) {
+    const scl_u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const scl_u32x4_v *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void scl_store16_nt(uint4 *p, const uint4 v) {
+    const scl_u32x4_v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<scl_u32x4_v *>(p));
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Round-2 back writer: 64-bit bit window -> per-lane LDS ring of 64 words -> whole 128-byte lines stored by quads.
 //
@@ -298,8 +310,13 @@ struct AnsBackWriterL {
             u8 *p = wg_out + (go_s - 128u + j16);
 #endif
 #if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
+#ifdef RF_NT_STORE
+            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
+            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
+#else
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
+#endif
 #else
             asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
 #endif
@@ -448,8 +465,13 @@ struct AnsBackWriterS {
             const uint4 q1 = *reinterpret_cast<const uint4 *>(r + (scl_quad_bcast<R>(rhi) + qj));
             u8 *p = wg_out + (scl_quad_bcast<R>(goff) - 128u + j16);
 #if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
+#ifdef RF_NT_STORE
+            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
+            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
+#else
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
+#endif
 #else
             asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
 #endif
@@ -591,11 +613,16 @@ struct CoopLineStore {
     }
 };
 
+
 struct Line128 {
     uint4 v[8];
     __device__ __forceinline__ void load(const uint4 *p) {
 #pragma unroll
+#ifdef RF_NT_LOAD
+        for (int i = 0; i < 8; ++i) v[i] = scl_load16_nt(p + i);
+#else
         for (int i = 0; i < 8; ++i) v[i] = p[i];
+#endif
     }
     // cooperative form: v[i] = this lane's piece of the line of lane (lane & 7) + 8 i; scl_transpose8 completes it
     __device__ __forceinline__ void load_coop(const uint4 *p, u64 step16) {
@@ -637,7 +664,11 @@ struct AnsBitReader {
         if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
+#ifdef RD_NT_LOAD
+            for (int i = 0; i < 8; ++i) pf[i] = scl_load16_nt(p + i);
+#else
             for (int i = 0; i < 8; ++i) pf[i] = p[i];
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -798,7 +829,11 @@ struct AnsBitReaderW {
         if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
+#ifdef RD_NT_LOAD
+            for (int i = 0; i < 8; ++i) pf[i] = scl_load16_nt(p + i);
+#else
             for (int i = 0; i < 8; ++i) pf[i] = p[i];
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {

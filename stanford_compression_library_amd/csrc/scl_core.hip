@@ -396,6 +396,58 @@ extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_of
                                   nullptr, d_scratch, stream);
 }
 
+// ---- host-side index of a framed block file (row f1 / f2) ----------------------------------------------
+// The serial walk EncodedBlockReader.get_block makes one record at a time (encoded_stream.py:196-225: 4-byte big-endian
+// payload size, payload; Padder.remove_byte_padding :48-58: 3-bit pad count, the pad bits, then the block's bits), for a
+// whole buffer: every header says where the next record starts, so the walk cannot be split -- but it is a few
+// instructions per record in C against microseconds in Python, and it is all the host has to do before a batched decode.
+// The block's own DATA_BLOCK_SIZE_BITS header (the first size_bits bits of its stream) is read out as well: the caller
+// sizes the decoder's output rows from it.
+extern "C" int scl_framed_index_host(const uint8_t *h_buf, uint64_t buf_size, uint32_t size_bits, uint64_t max_records,
+                                     uint64_t *h_bit_offset, uint64_t *h_nbits, uint64_t *h_block_size,
+                                     uint64_t *n_records, uint64_t *consumed) {
+    SCL_REQUIRE(n_records && consumed, "framed index: null count pointer");
+    *n_records = 0;
+    *consumed = 0;
+    SCL_REQUIRE(h_buf || buf_size == 0, "framed index: null buffer");
+    SCL_REQUIRE(size_bits <= 64, "framed index: size_bits %u > 64", size_bits);
+    SCL_REQUIRE(max_records == 0 || (h_bit_offset && h_nbits && h_block_size), "framed index: null output array");
+    u64 pos = 0, n = 0;
+    while (n < max_records && pos + 4 <= buf_size) {
+        const u64 payload = ((u64)h_buf[pos] << 24) | ((u64)h_buf[pos + 1] << 16) | ((u64)h_buf[pos + 2] << 8) | h_buf[pos + 3];
+        if (payload > buf_size - pos - 4) break;  // incomplete record: the caller reads on (or reports a truncated file)
+        if (payload == 0) {  // EncodedBlockWriter never writes one: at least the three pad-count bits are there
+            *n_records = n;
+            *consumed = pos;
+            scl_set_error("framed index: record %llu at byte %llu has an empty payload", (unsigned long long)n,
+                          (unsigned long long)pos);
+            return SCL_E_PARAM;
+        }
+        const u32 pad = h_buf[pos + 4] >> 5;
+        const u64 o = 8 * (pos + 4) + 3 + pad;
+        if (8 * payload < 3 + (u64)pad + size_bits) {
+            *n_records = n;
+            *consumed = pos;
+            scl_set_error("framed index: record %llu at byte %llu is shorter than its padding and its %u-bit size header",
+                          (unsigned long long)n, (unsigned long long)pos, size_bits);
+            return SCL_E_PARAM;
+        }
+        u64 v = 0;  // the first size_bits bits of the stream, MSB first
+        for (u32 b = 0; b < size_bits; ++b) {
+            const u64 bit = o + b;
+            v = (v << 1) | ((h_buf[bit >> 3] >> (7 - (bit & 7))) & 1u);
+        }
+        h_bit_offset[n] = o;
+        h_nbits[n] = 8 * payload - 3 - pad;
+        h_block_size[n] = v;
+        ++n;
+        pos += 4 + payload;
+    }
+    *n_records = n;
+    *consumed = pos;
+    return SCL_OK;
+}
+
 // ---- symbol histogram (row f3) ----------------------------------------------------------------------
 // 16 bytes per lane per load, per-wave private histograms in LDS (4 copies per workgroup: a wave's 64 lanes
 // collide on hot symbols, so sub-histograms by wave cut the ds_add serialisation), one global atomic per bin

@@ -1,0 +1,202 @@
+"""GPU: the BULK shape of the streaming driver (row f2; compressors/_stream_batch.py) -- file streams that move symbols as
+arrays of codes -- must write the same file bytes, decode to the same symbols and raise the same exceptions as the LIST
+shape (DataBlock lists, the reference's contract), whose bytes tests/test_gpu_stream_goldens.py pins on the reference's own
+files."""
+import os
+
+import numpy as np
+import pytest
+
+from stanford_compression_library_amd.backend import lib as backend_lib
+from stanford_compression_library_amd.backend.modeling import frequencies_from_counts
+from stanford_compression_library_amd.compressors import _stream_batch
+from stanford_compression_library_amd.compressors.arithmetic_coding import AECParams, ArithmeticDecoder, ArithmeticEncoder
+from stanford_compression_library_amd.compressors.probability_models import AdaptiveIIDFreqModel, FixedFreqModel
+from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+from stanford_compression_library_amd.core.data_block import DataBlock
+from stanford_compression_library_amd.core.data_stream import ListDataStream, TextFileDataStream, Uint8FileDataStream
+from stanford_compression_library_amd.core.encoded_stream import EncodedBlockReader, EncodedBlockWriter
+from stanford_compression_library_amd.core.prob_dist import Frequencies
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _coders(coder, fr):
+    if coder == "rans":
+        p = rANSParams(fr)
+        return rANSEncoder(p), rANSDecoder(p)
+    if coder == "tans":
+        p = tANSParams(fr, RANGE_FACTOR=1)
+        return tANSEncoder(p), tANSDecoder(p)
+    if coder == "aec":
+        pa = AECParams()
+        return (ArithmeticEncoder(pa, FixedFreqModel(fr, pa.MAX_ALLOWED_TOTAL_FREQ)),
+                ArithmeticDecoder(pa, FixedFreqModel(fr, pa.MAX_ALLOWED_TOTAL_FREQ)))
+    return RangeEncoder(RangeCoderParams(), fr), RangeDecoder(RangeCoderParams(), fr)
+
+
+def _encode_list(enc, symbols, block_size, path):
+    with EncodedBlockWriter(path) as w:
+        enc.encode(ListDataStream(list(symbols)), block_size, w)
+    return open(path, "rb").read()
+
+
+@pytest.mark.parametrize("coder", ["rans", "tans", "range", "aec"])
+@pytest.mark.parametrize("block_size,slab", [(777, 1 << 26), (1024, 1 << 26), (4096, 10_000), (500, 1500), (48, 64)])
+def test_byte_file_bulk_equals_list_shape(coder, block_size, slab, tmp_path, monkeypatch):
+    """several slabs (two alternating stages, records crossing the decoder's buffers, buffers that have to grow) or one"""
+    backend_lib.require_device()
+    monkeypatch.setattr(_stream_batch, "SLAB_BYTES", slab)
+    rng = np.random.default_rng(block_size)
+    data = rng.choice(256, size=23_456, p=np.r_[np.full(128, 0.006), np.full(128, 0.0018125)]).astype(np.uint8)
+    fr = frequencies_from_counts(np.bincount(data, minlength=256), 4096)
+    enc, dec = _coders(coder, fr)
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "b.bin", "out.bin"))
+    data.tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, block_size, w)
+    assert open(a, "rb").read() == _encode_list(enc, data.tolist(), block_size, b)
+    if slab == 1 << 26:  # and both equal the block loop over the one-block entry points (encode_block)
+        with EncodedBlockWriter(b) as w:
+            for i in range(0, data.size, block_size):
+                w.write_block(enc.encode_block(DataBlock(data[i:i + block_size].tolist())))
+        assert open(a, "rb").read() == open(b, "rb").read()
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == data.tobytes()
+    lst = ListDataStream([])
+    with EncodedBlockReader(a) as r:
+        dec.decode(r, lst)
+    assert lst.input_list == data.tolist()
+
+
+def test_sparse_alphabet_lut_and_unknown_symbol(tmp_path):
+    """an alphabet that is not 0..255 in order goes through the code table; a byte outside it raises the KeyError of the
+    per-block loop, naming the first such symbol"""
+    backend_lib.require_device()
+    alphabet = [200, 7, 10, 3, 255, 0]
+    rng = np.random.default_rng(2)
+    data = rng.choice(alphabet, size=9_999, p=[.4, .3, .1, .1, .05, .05]).astype(np.uint8)
+    fr = Frequencies(dict(zip(alphabet, [40, 30, 10, 10, 5, 5])))
+    enc, dec = rANSEncoder(rANSParams(fr)), rANSDecoder(rANSParams(fr))
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "b.bin", "out.bin"))
+    data.tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 1000, w)
+    assert open(a, "rb").read() == _encode_list(enc, data.tolist(), 1000, b)
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == data.tobytes()
+    bad = data.copy()
+    bad[4321], bad[7000] = 9, 11
+    bad.tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w, pytest.raises(KeyError) as e:
+        enc.encode(s, 1000, w)
+    assert e.value.args == (9,)
+    with pytest.raises(KeyError) as e2, EncodedBlockWriter(b) as w:
+        enc.encode(ListDataStream(bad.tolist()), 1000, w)
+    assert e2.value.args == e.value.args
+
+
+@pytest.mark.parametrize("alphabet", ["abcdefgh \n", "abéÿ \n", "abλ中 \n"])
+def test_text_file_bulk_equals_list_shape(alphabet, tmp_path):
+    """characters: one byte each when they all fit latin-1, else code points; encode_file / decode_file go this way"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(len(alphabet))
+    chars = list(alphabet)
+    text = "".join(rng.choice(chars, size=12_345))
+    fr = Frequencies(dict(zip(chars, frequencies_from_counts(np.array([text.count(c) for c in chars]), 1024).freq_list)))
+    enc, dec = rANSEncoder(rANSParams(fr)), rANSDecoder(rANSParams(fr))
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.txt", "a.bin", "b.bin", "out.txt"))
+    open(src, "w").write(text)
+    enc.encode_file(src, a, block_size=1000)
+    assert open(a, "rb").read() == _encode_list(enc, list(text), 1000, b)
+    dec.decode_file(a, out)
+    assert open(out).read() == text
+    open(src, "w").write(text[:5000] + "Z" + text[5000:])
+    with pytest.raises(KeyError) as e:
+        enc.encode_file(src, a, block_size=1000)
+    assert e.value.args == ("Z",)
+
+
+def test_wide_alphabet_text(tmp_path):
+    """more than 256 symbols: uint16 indices through the *_u16 entry points, code points on the host"""
+    backend_lib.require_device()
+    chars = [chr(0x100 + i) for i in range(300)]
+    rng = np.random.default_rng(9)
+    text = "".join(rng.choice(chars, size=4_000))
+    fr = Frequencies({ch: 1 + text.count(ch) for ch in chars})
+    enc, dec = RangeEncoder(RangeCoderParams(), fr), RangeDecoder(RangeCoderParams(), fr)
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.txt", "a.bin", "b.bin", "out.txt"))
+    open(src, "w").write(text)
+    enc.encode_file(src, a, block_size=333)
+    assert open(a, "rb").read() == _encode_list(enc, list(text), 333, b)
+    dec.decode_file(a, out)
+    assert open(out).read() == text
+
+
+def test_blocks_of_different_sizes_in_one_file(tmp_path):
+    """a framed file is any sequence of records: rows of unequal length are packed on the device"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(4)
+    data = rng.choice(6, size=7_000, p=[.4, .3, .1, .1, .05, .05]).astype(np.uint8)
+    fr = Frequencies(dict(zip(range(6), [40, 30, 10, 10, 5, 5])))
+    enc, dec = rANSEncoder(rANSParams(fr)), rANSDecoder(rANSParams(fr))
+    a, b, cat, out = (os.path.join(tmp_path, n) for n in ("a.bin", "b.bin", "cat.bin", "out.bin"))
+    _encode_list(enc, data[:3_000].tolist(), 700, a)
+    _encode_list(enc, data[3_000:].tolist(), 450, b)
+    open(cat, "wb").write(open(a, "rb").read() + open(b, "rb").read())
+    with EncodedBlockReader(cat) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == data.tobytes()
+
+
+def test_empty_and_truncated_files(tmp_path):
+    backend_lib.require_device()
+    fr = Frequencies(dict(zip(range(4), [4, 2, 1, 1])))
+    enc, dec = rANSEncoder(rANSParams(fr)), rANSDecoder(rANSParams(fr))
+    src, a, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "out.bin"))
+    open(src, "wb").close()
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 100, w)
+    assert os.path.getsize(a) == 0
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert os.path.getsize(out) == 0
+    np.random.default_rng(1).choice(4, size=1000).astype(np.uint8).tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 100, w)
+    blob = open(a, "rb").read()
+    for cut in (len(blob) - 1, len(blob) - 40, 3):
+        open(a, "wb").write(blob[:cut])
+        with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s, pytest.raises(AssertionError, match="truncated"):
+            dec.decode(r, s)
+    # a header that announces more bytes than the file has never sizes a buffer
+    open(a, "wb").write((0xFFFFFFF0).to_bytes(4, "big") + blob[4:200])
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s, pytest.raises(AssertionError, match="truncated"):
+        dec.decode(r, s)
+
+
+def test_adaptive_arithmetic_coder_keeps_the_block_loop(tmp_path):
+    """an adaptive model carries its state across blocks (quirk Q4): the file must equal the per-block loop's, whose bytes
+    tests/test_gpu_stream_goldens.py pins on the reference's own multi-block files"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(6)
+    data = rng.choice(4, size=3_000, p=[.5, .25, .15, .1]).astype(np.uint8)
+    pa = AECParams()
+    fr = Frequencies({i: 1 for i in range(4)})
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "b.bin", "out.bin"))
+    data.tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        ArithmeticEncoder(pa, AdaptiveIIDFreqModel(fr, pa.MAX_ALLOWED_TOTAL_FREQ)).encode(s, 500, w)
+    enc = ArithmeticEncoder(pa, AdaptiveIIDFreqModel(fr, pa.MAX_ALLOWED_TOTAL_FREQ))
+    with EncodedBlockWriter(b) as w:
+        for i in range(0, data.size, 500):
+            w.write_block(enc.encode_block(DataBlock(data[i:i + 500].tolist())))
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        ArithmeticDecoder(pa, AdaptiveIIDFreqModel(fr, pa.MAX_ALLOWED_TOTAL_FREQ)).decode(r, s)
+    assert open(out, "rb").read() == data.tobytes()
