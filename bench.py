@@ -29,6 +29,8 @@ The default 1-GPU run (no workload flags) also measures BASELINE.json's other si
 as `other_configs` to the same ONE JSON line: configs[1] at its literal size (65 536 chunks), configs[2] (range coder, 1 GiB
 of uniform bytes), configs[3] (order-1 adaptive arithmetic coder on a Markov-1 source: K = 16 at 1 GiB, K = 256 at 256 MiB)
 -- each with kernel times, `roofline` (frac + PMC traffic where a stamped pass exists) and both CPU baselines.
+`stream_file` (same run, static-model coders): the reference-API FILE path end to end on 256 MiB of the batch -- file I/O,
+PCIe both ways, kernels, framing (row f2; `summary.headline.file` = [encode, decode] MB/s); reported, never `value`.
 """
 import argparse
 import copy
@@ -179,6 +181,61 @@ def core_sha():
     for n in ("scl_common.h", "scl_core.hip"):
         h.update(n.encode() + b"\0" + open(os.path.join(d, n), "rb").read())
     return h.hexdigest()[:16]
+
+
+def stream_file_rate(w, res, n_bytes=1 << 28):
+    """Row f2 next to the kernels (rank 0, N = 1, after the timed region; never `value`): the reference-API file path end to
+    end -- ``encoder.encode(Uint8FileDataStream, chunk_len, EncodedBlockWriter)`` and ``decoder.decode(...)`` back -- on the
+    first 256 MiB of this batch written to a file: file I/O, PCIe both ways, symbol lookup, kernels, framing."""
+    import tempfile
+    import time
+
+    import numpy as np
+
+    from stanford_compression_library_amd.compressors.range_coder import RangeCoderParams, RangeDecoder, RangeEncoder
+    from stanford_compression_library_amd.compressors.rANS import rANSDecoder, rANSEncoder, rANSParams
+    from stanford_compression_library_amd.compressors.tANS import tANSDecoder, tANSEncoder, tANSParams
+    from stanford_compression_library_amd.core.data_stream import Uint8FileDataStream
+    from stanford_compression_library_amd.core.encoded_stream import EncodedBlockReader, EncodedBlockWriter
+    from stanford_compression_library_amd.core.prob_dist import Frequencies
+
+    sym = res["sym"]
+    chunk_len = int(sym.shape[1])
+    rows = min(int(sym.shape[0]), max(1, n_bytes // chunk_len))
+    data = sym[:rows].contiguous().cpu().numpy().reshape(-1)
+    fr = Frequencies({i: int(f) for i, f in enumerate(np.asarray(res["freq"]).tolist())})
+    if w.coder == "rans":
+        p = rANSParams(fr, NUM_BITS_OUT=w.num_bits_out, RANGE_FACTOR=w.range_factor)
+        enc, dec = rANSEncoder(p), rANSDecoder(p)
+    elif w.coder == "tans":
+        p = tANSParams(fr, RANGE_FACTOR=1)
+        enc, dec = tANSEncoder(p), tANSDecoder(p)
+    else:
+        enc, dec = RangeEncoder(RangeCoderParams(), fr), RangeDecoder(RangeCoderParams(), fr)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    src, mid, out = (os.path.join(d, f"scl_bench_{os.getpid()}_{n}.bin") for n in ("in", "enc", "out"))
+    try:
+        data.tofile(src)
+        te = td = float("inf")
+        for _ in range(3):  # the first repetition creates the model and the page-locked buffers
+            t0 = time.perf_counter()
+            with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(mid) as wr:
+                enc.encode(s, chunk_len, wr)
+            t1 = time.perf_counter()
+            with EncodedBlockReader(mid) as rd, Uint8FileDataStream(out, "wb") as s:
+                dec.decode(rd, s)
+            t2 = time.perf_counter()
+            te, td = min(te, t1 - t0), min(td, t2 - t1)
+        assert np.array_equal(np.fromfile(out, dtype=np.uint8), data), "file round trip differs from its input"
+        framed = os.path.getsize(mid)
+    finally:
+        for pth in (src, mid, out):
+            if os.path.exists(pth):
+                os.remove(pth)
+    return {"what": "encoder.encode(Uint8FileDataStream, chunk_len, EncodedBlockWriter) / decoder.decode(EncodedBlockReader, "
+                    "Uint8FileDataStream): file I/O + PCIe + kernels + framing, best of 3; not `value`",
+            "bytes": int(data.size), "framed_bytes": int(framed), "dir": d, "encode_MBps": round(data.size / te / 1e6, 1),
+            "decode_MBps": round(data.size / td / 1e6, 1), "round_trip_verified": True}
 
 
 def stream_bits(data_np, offs, nbits, c):
@@ -833,6 +890,13 @@ def main():
     wd.enter("per-rank statistics")
     per_rank_steps = D.gather_all([res["own_elapsed"] / args.steps * 1e3, enc_ms, dec_ms])
 
+    file_rate = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.coder in ("rans", "tans", "range"):
+        wd.enter("stream_file (reference-API file path, end to end)")
+        try:
+            file_rate = stream_file_rate(args, res)
+        except Exception as exc:  # an extra: it must not take the line with it
+            file_rate = {"error": f"{type(exc).__name__}: {exc}"}
     others = []
     if rank == 0 and world == 1 and args.default_workload and not args.no_other_configs:
         del res["sym"], res["enc"], res["model"]
@@ -899,6 +963,8 @@ def main():
         out["cpu_baseline"] = res.get("cpu_baseline")
         if "cpu_baseline_restatement" in res:
             out["cpu_baseline_restatement"] = res["cpu_baseline_restatement"]
+        if file_rate:
+            out["stream_file"] = file_rate
         if others:
             out["other_configs"] = others
         # LAST key, <= 1 KB: the driver's record keeps the tail of the line.  One entry per configuration -- kernel times
@@ -908,6 +974,8 @@ def main():
         # MBps = the configuration's round-trip value.
         summ = {"headline": summary_entry(r_enc, r_dec, r_dense, res.get("cpu_baseline"), res.get("cpu_baseline_restatement"))}
         summ["headline"]["MBps"] = round(value)
+        if file_rate and "encode_MBps" in file_rate:  # end-to-end file path [encode, decode] MB/s
+            summ["headline"]["file"] = [round(file_rate["encode_MBps"]), round(file_rate["decode_MBps"])]
         for o in others:
             tag = o["config"].split(":")[0].replace("configs", "c").replace(" on bytes", "b")
             if "_summary" in o:
