@@ -449,16 +449,20 @@ extern "C" int scl_framed_index_host(const uint8_t *h_buf, uint64_t buf_size, ui
 }
 
 // ---- symbol histogram (row f3) ----------------------------------------------------------------------
-// 16 bytes per lane per load, per-wave private histograms in LDS (4 copies per workgroup: a wave's 64 lanes
-// collide on hot symbols, so sub-histograms by wave cut the ds_add serialisation), one global atomic per bin
-// per workgroup at the end.
+// 16 bytes per lane per load; 32 sub-histograms in LDS, one per lane modulo 32, each 257 words long -- bin s of
+// sub-histogram j sits in bank (j + s) mod 32, so the 64 lanes of a ds_add that all hold the SAME symbol (runs of zeros,
+// text: the inputs a frequency model is built for) hit 32 different banks two at a time instead of one address 64 at a
+// time (round 5: a constant input 3.53 -> see tools/time_histogram.py; random bytes unchanged, they are bound by the rate
+// of LDS atomics as such).  One global atomic per non-empty bin and workgroup at the end.
+#define HG_SUB 32
+#define HG_STRIDE 257
 __global__ void __launch_bounds__(256) histogram_u8_kernel(const uint4 *__restrict__ sym16, u64 n16,
                                                           const u8 *__restrict__ tail, u32 n_tail,
                                                           unsigned long long *__restrict__ counts) {
-    __shared__ u32 s_h[4][256];
-    for (u32 i = threadIdx.x; i < 1024; i += 256) (&s_h[0][0])[i] = 0;
+    __shared__ u32 s_h[HG_SUB * HG_STRIDE];
+    for (u32 i = threadIdx.x; i < HG_SUB * HG_STRIDE; i += 256) s_h[i] = 0;
     __syncthreads();
-    u32 *h = s_h[threadIdx.x >> 6];
+    u32 *h = s_h + (threadIdx.x & (HG_SUB - 1)) * HG_STRIDE;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n16; i += (u64)gridDim.x * 256) {
         const uint4 v = sym16[i];
         const u32 w[4] = {v.x, v.y, v.z, v.w};
@@ -472,7 +476,9 @@ __global__ void __launch_bounds__(256) histogram_u8_kernel(const uint4 *__restri
     }
     if (blockIdx.x == 0 && threadIdx.x < n_tail) atomicAdd(&h[tail[threadIdx.x]], 1u);
     __syncthreads();
-    const u32 total = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    u32 total = 0;
+#pragma unroll 8
+    for (u32 j = 0; j < HG_SUB; ++j) total += s_h[j * HG_STRIDE + threadIdx.x];
     if (total) atomicAdd(&counts[threadIdx.x], (unsigned long long)total);
 }
 
@@ -482,7 +488,7 @@ extern "C" int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_co
     if (n == 0) return SCL_OK;
     const u64 n16 = n >> 4;
     u32 blocks = (u32)((n16 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;  // grid-stride above 8 workgroups per CU
+    if (blocks > 1024) blocks = 1024;  // grid-stride above 4 workgroups per CU (33 KiB of LDS each)
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(histogram_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint4 *>(d_sym), n16, d_sym + (n16 << 4), (u32)(n & 15),
@@ -493,6 +499,16 @@ extern "C" int scl_histogram_u8(const uint8_t *d_sym, uint64_t n, uint64_t *d_co
 
 // uint16 symbol indices (alphabets up to 65536, ABI 4): workgroup-private u32 histograms in LDS when the alphabet fits
 // (K <= 16384: 64 KiB), one global atomic per non-zero bin per workgroup; larger alphabets count straight into HBM.
+// 16 bytes (eight symbols) per lane per load over the 16-byte aligned body of the array (round 5: 2-byte loads moved
+// 1.0 TB/s); the few symbols in front of and behind it are counted by workgroup 0.
+__device__ __forceinline__ void hg16_count(u32 s, u32 K, u32 lds_bins, u32 *s_bins, unsigned long long *counts, u32 &n_bad) {
+    if (s >= K)
+        ++n_bad;
+    else if (lds_bins)
+        atomicAdd(&s_bins[s], 1u);
+    else
+        atomicAdd(&counts[s], 1ull);
+}
 __global__ void __launch_bounds__(256) histogram_u16_kernel(const u16 *__restrict__ sym, u64 n, u32 K, u32 lds_bins,
                                                            unsigned long long *__restrict__ counts,
                                                            u32 *__restrict__ bad) {
@@ -500,14 +516,23 @@ __global__ void __launch_bounds__(256) histogram_u16_kernel(const u16 *__restric
     for (u32 i = threadIdx.x; i < lds_bins; i += 256) s_bins[i] = 0;
     __syncthreads();
     u32 n_bad = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const u32 s = sym[i];
-        if (s >= K)
-            ++n_bad;
-        else if (lds_bins)
-            atomicAdd(&s_bins[s], 1u);
-        else
-            atomicAdd(&counts[s], 1ull);
+    // head: symbols in front of the first 16-byte boundary (at most 7), body: whole 16-byte pieces, tail: the rest
+    const u64 head = min((u64)(((16u - (u32)((uintptr_t)sym & 15u)) & 15u) >> 1), n);
+    const u64 n8 = (n - head) >> 3;
+    const uint4 *body = reinterpret_cast<const uint4 *>(sym + head);
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n8; i += (u64)gridDim.x * 256) {
+        const uint4 v = body[i];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            hg16_count(w[d] & 0xFFFFu, K, lds_bins, s_bins, counts, n_bad);
+            hg16_count(w[d] >> 16, K, lds_bins, s_bins, counts, n_bad);
+        }
+    }
+    if (blockIdx.x == 0) {
+        const u64 tail0 = head + (n8 << 3);
+        if (threadIdx.x < head) hg16_count(sym[threadIdx.x], K, lds_bins, s_bins, counts, n_bad);
+        if (tail0 + threadIdx.x < n && threadIdx.x < 8) hg16_count(sym[tail0 + threadIdx.x], K, lds_bins, s_bins, counts, n_bad);
     }
     if (n_bad) atomicAdd(bad, n_bad);
     __syncthreads();

@@ -113,6 +113,26 @@ def test_histograms_equal_reference_counts():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K", [300, 40000])
+def test_histogram_u16_any_alignment(K):
+    """the 16-byte body of the array is read eight symbols at a time; what lies in front of and behind it (an array that
+    starts anywhere, any length) is counted too, out-of-range indices included"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(K)
+    base = torch.from_numpy(rng.integers(0, K, 70_000).astype(np.int16 if K <= 32768 else np.uint16).view(np.int16)).cuda()
+    for start in range(0, 9):
+        for n in (0, 1, 6, 7, 8, 9, 15, 16, 17, 1000, 65_539):
+            view = base[start:start + n]
+            ref = np.bincount(view.cpu().numpy().view(np.uint16), minlength=K)
+            assert np.array_equal(histogram_u16(view, K), ref), (start, n)
+    bad = base[3:5003].clone()
+    bad[0], bad[4999] = K if K <= 32767 else -1, K if K <= 32767 else -1   # first (head) and last (tail) element
+    if K < 65536 and K <= 32767:
+        with pytest.raises(KeyError, match="2 symbol"):
+            histogram_u16(bad, K)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [257, 1000, 16384, 16385, 65536])
 def test_histogram_u16_equals_get_counts(K):
     """alphabets above 256 symbols: LDS-private bins up to 16384 symbols, straight global atomics above"""
