@@ -244,6 +244,11 @@ struct AnsBackWriterL {
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
         hi = __builtin_amdgcn_alignbit(v, hi, k);
     }
+    // push() in two halves (round 5): what two pushes of k0 and k1 bits move from hi into lo is what ONE funnel shift of the
+    // hi of before by k0 + k1 moves (k0 + k1 < 32) -- so a pair of symbols updates hi twice and lo once: three v_alignbit
+    // instead of four
+    __device__ __forceinline__ void push_hi(u32 v, u32 k) { hi = __builtin_amdgcn_alignbit(v, hi, k); }
+    __device__ __forceinline__ void fold_lo(u32 hi_before, u32 bits) { lo = __builtin_amdgcn_alignbit(hi_before, lo, bits); }
     // account for the `bits` (<= 26) pushed since the last call.  The subtraction's borrow IS the test "33 or more bits
     // pending" (v_sub_co_u32 + a branch on VCC: no separate compare); the wrapped counter's low 5 bits are the shift that
     // brings the oldest 32 bits down: (32 - n) mod 32 = 64 - n for 33 <= n <= 63.
@@ -322,15 +327,62 @@ struct AnsBackWriterL {
 #endif
         }
     }
+    // the two halves of quad_round (round 5 experiment, RF_FLUSH_SPLIT, off): the ring reads of ALL four rounds issued
+    // before the first store waits for any of them -- one LDS round trip per flush point instead of four in a row
+    template <int R>
+    __device__ __forceinline__ void quad_read(const char *lds, u32 f, u32 qbase, u32 j16, uint4 &q0, uint4 &q1) const {
+        if (scl_quad_bcast<R>(f)) {
+            const u32 l0 = scl_quad_bcast<R>(th4) + (132u + j16);
+            const char *r = lds + qbase + R * LANE_BYTES;
+            q0 = *reinterpret_cast<const uint4 *>(r + (l0 & 255u));
+            q1 = *reinterpret_cast<const uint4 *>(r + ((l0 + 64u) & 255u));
+        }
+    }
+    template <int R>
+    __device__ __forceinline__ void quad_store(u8 *wg_out, u32 f, u32 j16, const uint4 &q0, const uint4 &q1) const {
+        if (scl_quad_bcast<R>(f)) {
+#if RF_ABLATE & 4
+            u8 *p = wg_out + (scl_quad_bcast<R>(goff0) - 128u + j16);
+#else
+            u8 *p = wg_out + (scl_quad_bcast<R>(goff) - 128u + j16);
+#endif
+#if !(RF_ABLATE & 2)
+#ifdef RF_NT_STORE
+            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
+            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
+#else
+            *reinterpret_cast<uint4 *>(p) = q0;
+            *reinterpret_cast<uint4 *>(p + 64) = q1;
+#endif
+#else
+            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
+#endif
+        }
+    }
+#ifndef RF_FLUSH_SPLIT
+#define RF_FLUSH_SPLIT 0  // measured neutral (0.5593 vs 0.5597 ms over nine alternations of 100 launches) at ten registers more
+#endif
     // WAVE-UNIFORM call (all 64 lanes), at least every 64 symbols: <= 26 new words on top of <= 31 pending
     __device__ __forceinline__ void flush_quad(char *lds, u8 *wg_out, u32 tid) {
         const u32 f = pend4() >= 128u ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(f != 0)) {
             const u32 qbase = (tid & ~3u) * LANE_BYTES, j16 = 16u * (tid & 3u);
+#if RF_FLUSH_SPLIT
+            uint4 a0, a1, b0, b1, c0, c1, d0, d1;
+            quad_read<0>(lds, f, qbase, j16, a0, a1);
+            quad_read<1>(lds, f, qbase, j16, b0, b1);
+            quad_read<2>(lds, f, qbase, j16, c0, c1);
+            quad_read<3>(lds, f, qbase, j16, d0, d1);
+            quad_store<0>(wg_out, f, j16, a0, a1);
+            quad_store<1>(wg_out, f, j16, b0, b1);
+            quad_store<2>(wg_out, f, j16, c0, c1);
+            quad_store<3>(wg_out, f, j16, d0, d1);
+#else
             quad_round<0>(lds, wg_out, f, qbase, j16);
             quad_round<1>(lds, wg_out, f, qbase, j16);
             quad_round<2>(lds, wg_out, f, qbase, j16);
             quad_round<3>(lds, wg_out, f, qbase, j16);
+#endif
             if (f) {
                 goff -= 128u;
                 th4 ^= 128u;
@@ -414,6 +466,8 @@ struct AnsBackWriterS {
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
         hi = __builtin_amdgcn_alignbit(v, hi, k);
     }
+    __device__ __forceinline__ void push_hi(u32 v, u32 k) { hi = __builtin_amdgcn_alignbit(v, hi, k); }  // see AnsBackWriterL
+    __device__ __forceinline__ void fold_lo(u32 hi_before, u32 bits) { lo = __builtin_amdgcn_alignbit(hi_before, lo, bits); }
     template <u32 RING_OFF>
     __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check, by hand for the same reason
 #ifndef RF_NO_ASM_CHECK

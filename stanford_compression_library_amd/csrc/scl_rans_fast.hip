@@ -46,6 +46,9 @@
 #ifndef RD_PERM_PAIRS
 #define RD_PERM_PAIRS 1  // 0: one v_perm per decoded symbol
 #endif
+#ifndef RF_PAIR_FOLD
+#define RF_PAIR_FOLD 1  // 0: the window's low word follows every symbol (two v_alignbit per push, rounds 2-4)
+#endif
 #ifndef RF_COOP_STORE
 #define RF_COOP_STORE 1  // 0 (timing experiment): every lane stores its own lines
 #endif
@@ -109,7 +112,7 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh
         pos = q0 >> ((msh_rt >> 16) + 1u);
     }
     const u32 k = e.k_lo + pos;  // a plain add: a byte of another word would cost an SDWA form, 1.75 instead of 1.05 ns
-    o.push(x, k);
+    o.push_hi(x, k);             // (the caller folds the window's low word: once per pair of symbols, RF_PAIR_FOLD)
     x = rf_mad24(q0 >> pos, e.mf, (x >> k) + e.c);
     return k;
 }
@@ -129,7 +132,7 @@ __device__ __forceinline__ u32 rf_encode_entry_b(u32 &x, const EncEntry e, u32 m
                                                                // v_lshrrev_b32 reads five bits, the backend drops it)
     const u32 posb = (q0 >> ((msh_rt >> 16) & 0xFFu)) ? (msh_rt >> 24) : 0u;
     const u32 k = (e.k_lo >> 8) + posb;
-    o.push(x, k);
+    o.push_hi(x, k);
     x = rf_mad24(q0 >> posb, e.mf, (x >> k) + e.c);
     return k;
 }
@@ -193,11 +196,21 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
             bad |= (CHECK_SYM == 1) ? (t | w) : (t & w);
         }
         // (a pair releases at most 26 bits for NUM_BITS_OUT = 1 and at most 32 for b > 1: the window holds 32 + 32)
+        // the window's low word is brought up to date once per pair (NUM_BITS_OUT = 1: a pair releases < 32 bits) -- the
+        // hi of before the pair funnel-shifted by k0 + k1 is what the two pushes moved; b > 1 (up to 32 bits) folds per symbol
+        const u32 h0 = o.hi;
         const u32 k0 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o) : rf_encode_entry_b(x, cur.e[0], msh_rt, o);
+        const u32 h1 = o.hi;
+        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h0, k0);
         const u32 k1 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o) : rf_encode_entry_b(x, cur.e[1], msh_rt, o);
+        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h1, k1); else o.fold_lo(h0, k0 + k1);
         o.template check<RF_RING_OFF>(lds, k0 + k1);
+        const u32 h2 = o.hi;
         const u32 k2 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o) : rf_encode_entry_b(x, cur.e[2], msh_rt, o);
+        const u32 h3 = o.hi;
+        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h2, k2);
         const u32 k3 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o) : rf_encode_entry_b(x, cur.e[3], msh_rt, o);
+        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h3, k3); else o.fold_lo(h2, k2 + k3);
         o.template check<RF_RING_OFF>(lds, k2 + k3);
     }
 }
@@ -337,7 +350,10 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
         const u32 a = (u32)src[i] << 4;
         if (CHECK_SYM && (a >> 4) >= P.K) bad |= 0x80u;
         const EncEntry e1 = *reinterpret_cast<const EncEntry *>(tab + a);
-        o.template check<RF_RING_OFF>(lds, NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, e1, msh_rt, o) : rf_encode_entry_b(x, e1, msh_rt, o));
+        const u32 h_before = o.hi;
+        const u32 k_one = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, e1, msh_rt, o) : rf_encode_entry_b(x, e1, msh_rt, o);
+        o.fold_lo(h_before, k_one);
+        o.template check<RF_RING_OFF>(lds, k_one);
         if ((i & 15u) == 15u) RF_FLUSH();
     }
     RF_FLUSH();
