@@ -12,6 +12,7 @@
 //           with a Newton-refined v_rcp_f32), then ONE read of a slot -> {c, f, s} table; 128 symbols per store burst.
 #include <vector>
 
+#include "scl_ans_fast_io.h"  // scl_transpose8: the 8 x 8 register transpose behind the cooperative line store
 #include "scl_range_internal.h"
 
 #define RGE_THREADS 256
@@ -25,7 +26,9 @@
 // encode
 // ---------------------------------------------------------------------------------------------------
 struct RgOut {
-    u64 acc;   // pending bytes in memory order (byte j of the stream tail at bits [8j, 8j+8))
+    u64 acc;   // pending bytes as a big-endian number in its low cnt bits (the next byte of the stream is the most significant
+               // of them; what lies above bit cnt is left-over and never read) -- round 5: the bytes a symbol releases are then
+               // simply the high word of (u64)low << sh, no byte swap and no field extraction per symbol
     u32 cnt;   // number of pending BITS (a multiple of 8), < 32 between symbols -- bits, not bytes: every count on the
                // per-symbol path is a shift amount, and 8 * bytes was an instruction each time (round 4)
     u32 ra;    // LDS byte address of the ring word written next
@@ -37,8 +40,22 @@ struct RgOut {
     u8 *slot;
     uint4 held[4];  // first 64-byte half of the current line (stored together with the second half)
     u32 have_held;
+    // Cooperative line store (round 5): a lane storing its own 128-byte line makes every store instruction touch 64 different
+    // lines, 16 bytes of each -- the write shape that cost the rANS encoder a quarter of its time in round 2, and
+    // this encoder 0.2 of its 0.82 ms (RG_ABLATE_NOSTORE).  When the whole wave reaches a flush point with a complete line
+    // at the same position of its slot -- lanes of a batch of equally long chunks whose streams grow at the same rate
+    // (uniform bytes: configs[2]) do so at nearly every line -- the 64 lines are transposed in registers across the lanes
+    // l, l + 8, ..., l + 56 (scl_transpose8) and every store instruction writes eight WHOLE lines, eight lanes per line.
+    // Anything else (ragged batches, partial waves, lanes out of step) keeps the lane's own stores.
+    bool coop;      // wave-uniform: all 64 lanes code chunks of one length
+    u8 *coop_base;  // lane (l0, k) = (lane & 7, lane >> 3): piece k of the lines of the lanes l0 + 8 j
+    u64 stride;
 
-    __device__ __forceinline__ void init(u32 tid, u8 *slot_, u64 cap_) {
+    __device__ __forceinline__ void init(u32 tid, u8 *slot_, u64 cap_, bool coop_ = false) {
+        const u32 lane = tid & 63u;
+        coop = coop_;
+        stride = cap_;  // slots are out_stride apart and out_stride long
+        coop_base = slot_ - (u64)lane * cap_ + (u64)(lane & 7u) * cap_ + 16u * (lane >> 3);
         overflow = 0;
         cap = cap_;
         have_held = 0;
@@ -50,20 +67,60 @@ struct RgOut {
         nfl = 0;
         slot = slot_;
     }
-    // append nbits / 8 (0..4) bytes; byte j of `bytes` (bits [8j, 8j+8)) is the j-th byte in stream order
+    // append nbits / 8 (0..4) bytes: `bytes` is their big-endian number (the first byte in stream order the most significant)
     __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nbits) {
-        acc |= (u64)bytes << cnt;
+#if defined(RG_ABLATE) && (RG_ABLATE & 2)
+        asm volatile("" : : "v"(bytes), "v"(nbits));
+        return;
+#endif
+        acc = (acc << nbits) | bytes;
         cnt += nbits;
         if (cnt >= 32) {
-            *reinterpret_cast<u32 *>(lds + ra) = (u32)acc;
+            cnt -= 32;
+            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32((u32)(acc >> cnt));  // v_alignbit + v_perm
             ra = (ra + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
             ++pend;
-            acc >>= 32;
-            cnt -= 32;
         }
     }
     // 16 pending words -> 64 contiguous bytes; call at least every 16 symbols (<= 16 new words, ring of 32)
+    // COOP: compiled in for the table-free modes only -- the modes with a table sit at their 128 registers (four waves per
+    // SIMD) and spill 52-68 bytes with the transpose
+    template <bool COOP = false>
     __device__ __forceinline__ void maybe_flush(char *lds) {
+#ifndef RG_COOP_STORE
+#define RG_COOP_STORE 1
+#endif
+        if (RG_COOP_STORE && COOP && coop) {  // (wave-uniform; every lane of the wave makes this call)
+            const bool full = pend >= 16 && have_held;
+            if (__builtin_amdgcn_ballot_w64(full && nfl == (u32)__builtin_amdgcn_readfirstlane((int)nfl)) == ~0ull) {
+                const char *r = lds + fa;
+                u32 w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = *reinterpret_cast<const u32 *>(r + j * RGE_THREADS * 4);
+                uint4 a[8] = {held[0], held[1], held[2], held[3], make_uint4(w[0], w[1], w[2], w[3]),
+                              make_uint4(w[4], w[5], w[6], w[7]), make_uint4(w[8], w[9], w[10], w[11]),
+                              make_uint4(w[12], w[13], w[14], w[15])};
+                if (4 * (u64)nfl + 64 <= cap) {  // the same for all lanes
+                    scl_transpose8(a);
+                    u8 *p = coop_base + 4 * (u64)(nfl - 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#ifndef RG_ABLATE_NOSTORE
+                        *reinterpret_cast<uint4 *>(p + (u64)(8 * j) * stride) = a[j];
+#else
+                        asm volatile("" : : "v"(a[j].x), "v"(p));
+#endif
+                    }
+                } else {
+                    overflow = 1;
+                }
+                have_held = 0;
+                nfl += 16;
+                pend -= 16;
+                fa ^= 16 * RGE_THREADS * 4;
+                return;
+            }
+        }
         if (pend >= 16) {
             const char *r = lds + fa;
             u32 w[16];
@@ -123,7 +180,7 @@ struct RgOut {
             w32[nfl + j] = *reinterpret_cast<const u32 *>(lds + a);
             a = (a + RGE_THREADS * 4) & (RGE_RING_BYTES - 1);
         }
-        for (u32 j = 0; j < cnt_bytes; ++j) slot[words * 4 + j] = (u8)(acc >> (8 * j));
+        for (u32 j = 0; j < cnt_bytes; ++j) slot[words * 4 + j] = (u8)(acc >> (cnt - 8 * (j + 1)));
         return words * 4 + cnt_bytes;
     }
 };
@@ -158,8 +215,8 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
     return true;
 }
 
-// shrink_range (:88-105) + normalize (:107-179) for one symbol; returns its released bytes (0..3 of them, first one in
-// the low byte) and their number IN BITS.  The normalisation is a closed form: the loop first releases every leading byte on which low and
+// shrink_range (:88-105) + normalize (:107-179) for one symbol; returns its released bytes (0..3 of them, as a big-endian
+// number) and their number IN BITS.  The normalisation is a closed form: the loop first releases every leading byte on which low and
 // low + range agree (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them (range > 0, so
 // the two values differ and nb1 <= 3); it goes on only if the range left after that is below BOTTOM (the carry-less
 // reset, :136-178) -- rare.  ONE branch per symbol covers everything rare: the reference's literal loop, a symbol that
@@ -184,11 +241,15 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
     // 8 * (leading common bytes): clz & 0x18 (the two values differ, so clz <= 31 and the count <= 3 bytes)
     const u32 sh = (u32)__builtin_clz(low0 ^ (low0 + range0)) & 0x18u;
     const u32 range_s = range0 << sh;
-    bytes = __builtin_amdgcn_ubfe(__builtin_bswap32(low0), 0, sh);  // the low sh bits (sh = 0: none)
+    const u64 l64 = ((u64)low0) << sh;  // one v_lshlrev_b64: the released bytes (big-endian) : the new low
+    bytes = (u32)(l64 >> 32);
     nb = sh;  // in BITS
-    low = low0 << sh;
+    low = (u32)l64;
     range = range_s;
-    if (__builtin_expect(range_s < RG_BOTTOM, 0)) {
+#ifndef RG_ABLATE
+#define RG_ABLATE 0  // timing experiments (wrong output): 1 = no rare-path branch, 2 = nothing leaves the byte accumulator
+#endif
+    if (!(RG_ABLATE & 1) && __builtin_expect(range_s < RG_BOTTOM, 0)) {
         low = low0;
         range = range0;
         bytes = 0;
@@ -198,7 +259,7 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
             const bool settled = ((low ^ (low + range)) < RG_TOP);
             if (!settled && range >= RG_BOTTOM) break;
             if (!settled) range = (0u - low) & (RG_BOTTOM - 1);  // (MASK + 1 - low) & (BOTTOM - 1), :172
-            bytes |= (low >> 24) << (8 * j);
+            bytes = (bytes << 8) | (low >> 24);
             nb += 8;
             low <<= 8;
             range <<= 8;
@@ -256,14 +317,14 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0, z0, zn, o, lds);
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1, b0, n0, o, lds);
             if (n0 + n1 <= 32) {  // each <= 24
-                o.put_bytes(lds, b0 | (b1 << n0), n0 + n1);
+                o.put_bytes(lds, (b0 << n1) | b1, n0 + n1);
             } else {
                 o.put_bytes(lds, b0, n0);
                 o.put_bytes(lds, b1, n1);
             }
         }
     }
-    o.maybe_flush(lds);
+    o.template maybe_flush<RG_UNI(MODE)>(lds);
 }
 
 template <int MODE>
@@ -287,8 +348,10 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
     RgOut o;
-    o.init(threadIdx.x, out + c * out_stride, out_stride);
-    o.put_bytes(lds, __builtin_bswap32(n), 32);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
+    // whole wave, equally long chunks: every lane reaches every flush point, so the wave can store lines cooperatively
+    const bool coop = __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
+    o.init(threadIdx.x, out + c * out_stride, out_stride, coop);
+    o.put_bytes(lds, n, 32);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
     u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
     RgDivM md;
     md.m_log2 = P.m_log2;
@@ -334,10 +397,10 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
         u32 bytes, nb, z0 = 0, zn = 0;
         rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a), md, bytes, nb, z0, zn, o, lds);
         o.put_bytes(lds, bytes, nb);
-        if ((i & 15u) == 15u) o.maybe_flush(lds);
+        if ((i & 15u) == 15u) o.template maybe_flush<RG_UNI(MODE)>(lds);
     }
-    o.maybe_flush(lds);
-    o.put_bytes(lds, __builtin_bswap32(low), 32);  // flush :181-186: the four bytes of low, most significant first
+    o.template maybe_flush<RG_UNI(MODE)>(lds);
+    o.put_bytes(lds, low, 32);  // flush :181-186: the four bytes of low, most significant first
     const u64 total_bytes = o.finish(lds);
     out_bit_off[c] = c * out_stride * 8;
     out_nbits[c] = (u32)(total_bytes * 8);

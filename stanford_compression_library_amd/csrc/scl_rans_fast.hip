@@ -142,8 +142,14 @@ __device__ __forceinline__ u32 rf_encode_entry_b(u32 &x, const EncEntry e, u32 m
                                                                // v_lshrrev_b32 reads five bits, the backend drops it)
     const u32 posb = (q0 >> ((msh_rt >> 16) & 0xFFu)) ? (msh_rt >> 24) : 0u;
     const u32 k = (e.k_lo >> 8) + posb;
+#if RF_SHIFT64
+    const u64 t = ((((u64)x) << 32) | o.hi) >> k;  // k <= 16
+    o.hi = (u32)t;
+    x = rf_mad24(q0 >> posb, e.mf, (u32)(t >> 32) + e.c);
+#else
     o.push_hi(x, k);
     x = rf_mad24(q0 >> posb, e.mf, (x >> k) + e.c);
+#endif
     return k;
 }
 
