@@ -215,6 +215,36 @@ __device__ __forceinline__ bool rg_needs_byte(u32 low, u32 &range) {
     return true;
 }
 
+// The common case of one symbol and nothing else (round 5): shrink_range, then the leading bytes low and low + range
+// agree on.  No branch, no loop; returns the range left after them -- below BOTTOM means the carry-less reset is due and
+// none of what this returned holds (the caller replays the symbol with rg_encode_symbol).  May be called on a state that is
+// itself such a discarded result (the second symbol of a pair whose first one was rare): everything here is defined for
+// any input (v_ffbh_u32 of 0 is -1, written as the instruction: __builtin_clz(0) is not).
+template <int MODE>
+__device__ __forceinline__ u32 rg_fast_symbol(u32 &low, u32 &range, const uint2 e, const RgDivM &md, u32 &bytes, u32 &nb) {
+    const u32 r = rg_range_over_m<MODE>(range, md);
+    u32 low0, range0;
+    if (RG_UNI(MODE)) {
+        range0 = (MODE == 3) ? r : (r << md.t);
+        low0 = __umul24(e.x, range0) + low;
+    } else if (RG_R24(MODE)) {
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(low0) : "v"(e.x), "v"(r), "v"(low));
+        range0 = __umul24(r, e.y);
+    } else {
+        low0 = low + e.x * r;
+        range0 = r * e.y;
+    }
+    u32 lz;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(low0 ^ (low0 + range0)));
+    const u32 sh = lz & 0x18u;
+    const u64 l64 = ((u64)low0) << sh;
+    bytes = (u32)(l64 >> 32);
+    nb = sh;
+    low = (u32)l64;
+    range = range0 << sh;
+    return range;
+}
+
 // shrink_range (:88-105) + normalize (:107-179) for one symbol; returns its released bytes (0..3 of them, as a big-endian
 // number) and their number IN BITS.  The normalisation is a closed form: the loop first releases every leading byte on which low and
 // low + range agree (low + range never carries out of 32 bits), nb1 = clz(low ^ (low + range)) / 8 of them (range > 0, so
@@ -313,7 +343,33 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
             if (!RG_UNI(MODE)) bad = max(bad, max(a[j], a[j + 1]));
-            u32 b0, n0, b1, n1, z0 = 0, zn = 0;  // n0, n1: bits
+            u32 b0, n0, b1, n1;  // n0, n1: bits
+#ifndef RG_PAIR_REPLAY
+#define RG_PAIR_REPLAY 1  // 0: one rare-path branch per symbol and a third for pairs of more than four bytes (rounds 2-4)
+#endif
+#if RG_PAIR_REPLAY
+            // Both symbols on the common path, unconditionally; ONE test and one branch per pair for everything else -- a
+            // carry-less reset in either symbol, more than a word of bytes from the two together -- whose lanes replay the
+            // pair from the state of before it, symbol by symbol, with the exact routine.  (Was: a branch per symbol, a
+            // third for the byte count, 20 scalar instructions and three taken branches per pair.)
+            const uint2 e0 = rg_entry<MODE>(tab, a[j]), e1 = rg_entry<MODE>(tab, a[j + 1]);
+            const u32 low_s = low, range_s = range;
+            const u32 r0 = rg_fast_symbol<MODE>(low, range, e0, md, b0, n0);
+            const u32 r1 = rg_fast_symbol<MODE>(low, range, e1, md, b1, n1);
+            const u32 nn = n0 + n1;
+            if (__builtin_expect((min(r0, r1) < RG_BOTTOM) | (nn > 32), 0)) {
+                low = low_s;
+                range = range_s;
+                u32 z0 = 0, zn = 0, z1 = 0, z1n = 0;
+                rg_encode_symbol<MODE>(low, range, e0, md, b0, n0, z0, zn, o, lds);
+                o.put_bytes(lds, b0, n0);
+                rg_encode_symbol<MODE>(low, range, e1, md, b1, n1, z1, z1n, o, lds);
+                o.put_bytes(lds, b1, n1);
+            } else {
+                o.put_bytes(lds, (b0 << n1) | b1, nn);
+            }
+#else
+            u32 z0 = 0, zn = 0;
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0, z0, zn, o, lds);
             rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1, b0, n0, o, lds);
             if (n0 + n1 <= 32) {  // each <= 24
@@ -322,6 +378,7 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
                 o.put_bytes(lds, b0, n0);
                 o.put_bytes(lds, b1, n1);
             }
+#endif
         }
     }
     o.template maybe_flush<RG_UNI(MODE)>(lds);
@@ -696,8 +753,13 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
             a[b] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
+#ifdef RGD_ABLATE_NOSTORE  // timing experiment
+#pragma unroll
+        for (int b = 0; b < 8; ++b) asm volatile("" : : "v"(a[b].x), "v"(a[b].y), "v"(a[b].z), "v"(a[b].w), "v"(p));
+#else
 #pragma unroll
         for (int b = 0; b < 8; ++b) p[b] = a[b];
+#endif
     }
     for (; i < n; ++i) {  // ragged tail
         dst[i] = (u8)rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);

@@ -195,3 +195,41 @@ def test_library_names_its_kernels_like_rocprof(dev):
         assert names("scl_rans_kernel_names", cases[0][2], 1000) == ("rans_encode_generic", "rans_decode_generic")
     finally:
         L.scl_set_any_parameter_kernels(prev)
+
+
+@pytest.mark.parametrize("table", ["uniform1", "uniform16"])
+def test_range_cooperative_line_store(table, dev):
+    """the table-free range encoder stores its lines cooperatively (eight lanes per line after a register transpose) when a
+    whole wave of equally long chunks reaches a flush point in step -- streams equal the oracle's for whole waves (random
+    bytes keep their lanes within a byte or two of each other: most lines go out cooperatively, the rest lane by lane), for
+    a partial last wave, and for slots too small for their stream (every chunk reports CAPACITY, nothing is written behind
+    the last slot)"""
+    from stanford_compression_library_amd.backend.models import EncodedBatch
+
+    freq = np.ones(256, dtype=np.int64) if table == "uniform1" else np.full(256, 16, dtype=np.int64)
+    model = models.RangeModel(freq.tolist(), 32, 32)
+    rng = np.random.default_rng(len(table))
+    n_chunks, chunk_len = 64 * 3 + 17, 1536
+    sym_np = rng.integers(0, 256, (n_chunks, chunk_len), dtype=np.uint8)
+    sym = torch.from_numpy(sym_np).to(dev)
+    enc = model.encode_batch(sym)
+    torch.cuda.synchronize()
+    assert not enc.status.any().item()
+    data, offs, nbits = enc.data.cpu().numpy(), enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
+    for c in list(range(0, n_chunks, 13)) + [63, 64, 191, 192, n_chunks - 1]:
+        packed, nb = orc.range_encode(sym_np[c], freq.tolist())
+        assert nb == nbits[c] and offs[c] % 8 == 0
+        assert np.array_equal(data[offs[c] // 8: offs[c] // 8 + (nb + 7) // 8], packed[: (nb + 7) // 8]), c
+    out, lens, used, status = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len)
+    torch.cuda.synchronize()
+    assert torch.equal(out, sym) and not status.any().item()
+    # slots of 1024 bytes for streams of ~1544: CAPACITY on every chunk, the bytes behind the last slot untouched
+    stride = 1024
+    buf = torch.full((n_chunks * stride + 16 + 4096,), FILL, dtype=torch.uint8, device=dev)
+    small = EncodedBatch(buf[: n_chunks * stride + 16], stride, torch.empty(n_chunks, dtype=torch.int64, device=dev),
+                         torch.empty(n_chunks, dtype=torch.int32, device=dev),
+                         torch.empty(n_chunks, dtype=torch.int32, device=dev), n_chunks)
+    model.encode_batch(sym, out=small)
+    torch.cuda.synchronize()
+    assert bool((small.status & backend_lib.ST_CAPACITY).bool().all().item())
+    assert bool((buf[n_chunks * stride + 16:] == FILL).all().item())
