@@ -546,6 +546,7 @@ struct RgIn {  // forward bit reader over a per-lane LDS word ring (same scheme 
     }
     __device__ __forceinline__ u32 consumed() const { return 32 * nrd - (u32)sh - bias; }
     __device__ __forceinline__ u32 look() const { return __builtin_amdgcn_alignbit(A, B, (u32)sh); }
+    __device__ __forceinline__ u32 look(const char *) const { return look(); }
     __device__ __forceinline__ void advance(const char *lds, u32 nb) {  // nb <= 32
         sh -= (int)nb;
         if (sh < 0) {
@@ -595,8 +596,63 @@ __device__ __forceinline__ u32 rg_div32(u32 d, u32 r) {
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
 // LUT: totals up to 4096 find the symbol in a slot -> symbol table; larger ones (up to BOTTOM = 2^16) by an 8-step
 // binary search on the cumulative counts (K = alphabet size rides in md.k)
+// The common case of one decoded symbol and nothing else (round 5, RGD_PAIR): search, shrink_range, the leading bytes low
+// and low + range agree on -- taken from `lk`, the next 32 bits of the stream, which are consumed from its top: ONE 64-bit
+// shift of state : lk yields the new state and the look-ahead that is left.  No reader access, no branch; returns the
+// symbol, `nb` bits consumed and `left` = the range after them (below BOTTOM: the carry-less reset is due and nothing
+// returned here holds -- the caller replays the symbol with rg_decode_symbol).  Defined for any input, like
+// rg_fast_symbol.
 template <int MODE, bool LUT, bool DIV32>
-__device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, RgIn &r, char *lds, const char *tab,
+__device__ __forceinline__ u32 rg_decode_fast(u32 &low, u32 &range, u32 &state, u32 &lk, u32 &nb, u32 &left,
+                                              const char *tab, const RgDivM &md, u32 slot_max) {
+    const u32 rr = rg_range_over_m<MODE>(range, md);
+    u32 q = DIV32 ? rg_div32(state - low, rr) : rg_div(state - low, rr);
+    q = min(q, slot_max);
+    u32 s;
+    uint2 e;
+    if (RG_UNI(MODE)) {
+        s = (MODE == 3) ? q : (q >> md.t);
+        e = make_uint2(0u, 0u);
+    } else if (LUT) {
+        e = *reinterpret_cast<const uint2 *>(tab + q * 8);
+        s = e.x >> 24;
+        if (!DIV32) e.x &= 0xFFFFFFu;
+    } else {
+        s = 0;
+#pragma unroll
+        for (u32 b = 128; b > 0; b >>= 1) {
+            const u32 t = s + b;
+            const u32 ct = *reinterpret_cast<const u32 *>(tab + min(t, 255u) * 8);
+            s = (t < md.k && ct <= q) ? t : s;
+        }
+        e = *reinterpret_cast<const uint2 *>(tab + s * 8);
+    }
+    u32 low0, range0;
+    if (RG_UNI(MODE)) {
+        range0 = (MODE == 3) ? rr : (rr << md.t);
+        low0 = __umul24(s, range0) + low;
+    } else if (DIV32) {
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(low0) : "v"(e.x), "v"(rr), "v"(low));
+        range0 = __umul24(rr, e.y);
+    } else {
+        low0 = low + e.x * rr;
+        range0 = rr * e.y;
+    }
+    u32 lz;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(low0 ^ (low0 + range0)));
+    const u32 sh = lz & 0x18u;
+    const u64 t = ((((u64)state) << 32) | lk) << sh;
+    state = (u32)(t >> 32);
+    lk = (u32)t;
+    low = low0 << sh;
+    range = range0 << sh;
+    nb = sh;
+    left = range;
+    return s;
+}
+
+template <int MODE, bool LUT, bool DIV32, typename Reader>
+__device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state, Reader &r, char *lds, const char *tab,
                                                 const RgDivM &md, u32 slot_max) {
     const u32 rr = rg_range_over_m<MODE>(range, md);
     u32 q = DIV32 ? rg_div32(state - low, rr) : rg_div(state - low, rr);
@@ -636,7 +692,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         low += e.x * rr;
         range = rr * e.y;
     }
-    const u32 lk = r.look();
+    const u32 lk = r.look(lds);
     // closed form of the common case computed unconditionally, ONE branch for everything rare (see rg_encode_symbol)
     const u32 low0 = low, range0 = range, state0 = state;
     const u32 nb1 = (u32)__builtin_clz(low0 ^ (low0 + range0)) >> 3;
@@ -664,7 +720,7 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
         r.advance(lds, 8 * nb);
         adv = 0;
         while (nb == 4 && rg_needs_byte(low, range)) {  // mirror of the encoder's guard
-            state = (state << 8) | (r.look() >> 24);
+            state = (state << 8) | (r.look(lds) >> 24);
             r.advance(lds, 8);
             low <<= 8;
             range <<= 8;
@@ -709,10 +765,22 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         if (status) status[c] = SCL_ST_TRUNCATED;
         return;
     }
+#ifndef RGD_PAIR
+#define RGD_PAIR 1  // 0: the round-1..4 reader (two ring words in registers, advanced under a branch per symbol)
+#endif
+#if RGD_PAIR
+    // the rANS decoder's windowless reader (scl_ans_fast_io.h): the 32 bits at the position come straight out of the ring,
+    // once per PAIR of symbols; nothing is advanced under a branch
+    AnsBitReaderW<RGD_THREADS> r;
+    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
+    u32 n = r.get(lds, 32);
+    u32 state = r.get(lds, 32);  // the first four bytes of the body (:289-291)
+#else
     RgIn r;
     r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get32(lds);
     u32 state = r.get32(lds);  // the first four bytes of the body (:289-291)
+#endif
     out_lens[c] = n;
     if (n > out_cap) {
         st |= SCL_ST_CAPACITY;
@@ -741,12 +809,42 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 u32 o = 0;
+#if RGD_PAIR
+                // Both symbols of a pair on the common path out of ONE 32-bit look-ahead, unconditionally; one test and one
+                // branch per pair for everything else (a carry-less reset in either symbol, more than 32 bits for the two):
+                // those lanes replay the pair from the state of before it with the exact routine.
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    u32 lk = r.look(lds);
+                    const u32 low_s = low, range_s = range, state_s = state;
+                    u32 n0, n1, l0, l1;
+                    u32 s0 = rg_decode_fast<MODE, LUT, DIV32>(low, range, state, lk, n0, l0, tab, md, slot_max);
+                    u32 s1 = rg_decode_fast<MODE, LUT, DIV32>(low, range, state, lk, n1, l1, tab, md, slot_max);
+                    const u32 nn = n0 + n1;
+#ifdef RGD_ABLATE_NOSLOW  // timing experiment (wrong output on rare lanes): no replay code at all
+                    if (0) {
+#else
+                    if (__builtin_expect((min(l0, l1) < RG_BOTTOM) | (nn > 32), 0)) {
+#endif
+                        low = low_s;
+                        range = range_s;
+                        state = state_s;
+                        s0 = rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
+                        s1 = rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
+                    } else {
+                        r.advance(lds, nn);
+                    }
+                    o |= (s0 << (8 * j)) | (s1 << (8 * j + 8));
+                }
+                if (d & 1) r.maybe_refill(lds);  // every eight symbols: <= 8 words even if each took the four-byte path
+#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32 s = rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
                     o |= s << (8 * j);
                 }
                 r.maybe_refill(lds);
+#endif
                 asm volatile("" : "+v"(o) : : "memory");
                 ow[d] = o;
             }
