@@ -1064,6 +1064,9 @@ struct AnsFwdWriter {
             const uint4 q2 = make_uint4(w[8], w[9], w[10], w[11]), q3 = make_uint4(w[12], w[13], w[14], w[15]);
             if (have_held) {  // second half of the line whose first half is held
                 uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
+#ifdef FW_ABLATE_NOSTORE  // timing experiment
+                asm volatile("" : : "v"(held[0].x), "v"(held[1].x), "v"(held[2].x), "v"(held[3].x), "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
+#else
                 p[0] = held[0];
                 p[1] = held[1];
                 p[2] = held[2];
@@ -1072,6 +1075,7 @@ struct AnsFwdWriter {
                 p[5] = q1;
                 p[6] = q2;
                 p[7] = q3;
+#endif
                 have_held = 0;
             } else {
                 held[0] = q0;
