@@ -13,7 +13,8 @@ run() { echo "== $*" >> $O; env "$@" timeout 1500 python tools/stress_fast_kerne
 run MODEL=rans REPS=30
 run MODEL=rans_b8 REPS=10
 run MODEL=tans REPS=10
-run MODEL=range REPS=5
+run MODEL=range REPS=20
+run MODEL=range_uniform1 REPS=20
 run MODEL=order1 REPS=40
 run MODEL=iid NCHUNKS=65536 REPS=40
 run MODEL=fixed REPS=10

@@ -9,8 +9,11 @@ from stanford_compression_library_amd.backend import models
 dev = torch.device("cuda:0")
 n_chunks, chunk_len = int(os.environ.get("NCHUNKS", 262144)), 4096
 mode = os.environ.get("MODEL", "fixed")
-if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "rans_m3000", "fixed_k64", "rans_b8"):
+if mode in ("fixed", "rans", "tans", "range", "range_uniform1", "iid", "rans_k64", "rans_k200", "rans_m3000", "fixed_k64",
+            "rans_b8"):
     freq = bench_data.t256_table()
+    if mode == "range_uniform1":  # configs[2]: f = 1, M = 256 -- the table-free range kernels (cooperative line stores)
+        freq = np.ones(256, dtype=np.int64)
     if mode in ("rans_k64", "rans_k200", "fixed_k64"):  # alphabets below 256: the symbol-checking encoder variants
         K = 64 if mode.endswith("k64") else 200
         freq = freq[:K].copy()
@@ -28,7 +31,8 @@ if mode in ("fixed", "rans", "tans", "range", "iid", "rans_k64", "rans_k200", "r
              "rans_b8": lambda: models.RansModel(freq.tolist(), 1 << 8, 8, 32),  # NUM_BITS_OUT = 8 kernels
              "fixed_k64": lambda: models.AecModel(0, freq.tolist(), int(freq.size), 0, 1 << 30, 32, 32),
              "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
-             "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
+             "range": lambda: models.RangeModel(freq.tolist(), 32, 32),
+             "range_uniform1": lambda: models.RangeModel(freq.tolist(), 32, 32)}[mode]()
 elif mode == "order1_k256":  # scl_aec_wide.hip (device-memory rows): NCHUNKS=65536 keeps the tables at 17.8 GB
     sym = bench_data.markov1_chunks_device(256, n_chunks, chunk_len, seed=901, device=dev)
     model = models.AecModel(2, None, 256, 1, 1 << 30, 32, 32)
