@@ -18,11 +18,12 @@ def symbols_to_indices(data_block: DataBlock, index_of: dict) -> np.ndarray:
     data = data_block.data_list
     if isinstance(data, np.ndarray):
         data = data.tolist()
-    return np.fromiter((index_of[s] for s in data), dtype=index_dtype(len(index_of)), count=len(data))
+    # (map over the dict's own __getitem__: no generator frame per symbol -- half the time of a generator expression)
+    return np.fromiter(map(index_of.__getitem__, data), dtype=index_dtype(len(index_of)), count=len(data))
 
 
 def indices_to_block(idx: np.ndarray, alphabet: list) -> DataBlock:
-    return DataBlock([alphabet[i] for i in idx.tolist()])
+    return DataBlock(list(map(alphabet.__getitem__, idx.tolist())))
 
 
 def bitarray_to_packed(bits: BitArray):
