@@ -590,7 +590,17 @@ __device__ __forceinline__ u32 rg_div32(u32 d, u32 r) {
     u32 q;  // q or q - 1
     asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(qf));
     const u32 rem = d - __umul24(q, r);   // q < 2^17, r < 2^24; rem in [0, 2r)
+#ifndef RGD_SUBB
+#define RGD_SUBB 1  // 0: v_cmp_ge + v_addc (2.8 + 1.9 ns) instead of v_sub_co + v_subb (1.9 + 1.9)
+#endif
+#if RGD_SUBB
+    u32 t, qn;  // q + 1 - [rem < r]: the borrow of rem - r IS the test
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_subb_co_u32 %1, vcc, %4, -1, vcc"
+        : "=&v"(t), "=v"(qn) : "v"(rem), "v"(r), "v"(q) : "vcc");
+    return qn;
+#else
     return q + (rem >= r ? 1u : 0u);
+#endif
 }
 
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
@@ -644,8 +654,20 @@ __device__ __forceinline__ u32 rg_decode_fast(u32 &low, u32 &range, u32 &state, 
     const u64 t = ((((u64)state) << 32) | lk) << sh;
     state = (u32)(t >> 32);
     lk = (u32)t;
+#ifndef RGD_PACKED_SHIFT
+#define RGD_PACKED_SHIFT 1  // 0: low and range shifted by two instructions
+#endif
+#if RGD_PACKED_SHIFT
+    // low and low + range agree on their top sh bits, so range0 < 2^(32 - sh): shifting the pair low0 : range0 left by sh
+    // moves nothing of range0 into low0's word -- one 64-bit shift for both (the bytes leaving the top of low0 are not
+    // needed here: the decoder reads them from the stream)
+    const u64 lr = ((((u64)low0) << 32) | range0) << sh;
+    low = (u32)(lr >> 32);
+    range = (u32)lr;
+#else
     low = low0 << sh;
     range = range0 << sh;
+#endif
     nb = sh;
     left = range;
     return s;
