@@ -45,6 +45,15 @@ def _check(cond, msg):
         raise AssertionError(msg)
 
 
+def _bulk_capable(stream, bulk: str, per_symbol) -> bool:
+    """does ``stream`` offer the bulk method AND still move symbols the way the class that defines it does?  A subclass that
+    overrides ``get_block`` / ``get_symbol`` (``write_block`` / ``write_symbol``) -- a filter, a counter, a transform --
+    must see every symbol: it gets the LIST shape."""
+    cls = type(stream)
+    owner = next((k for k in cls.__mro__ if bulk in k.__dict__), None)
+    return owner is not None and all(getattr(cls, m, None) is getattr(owner, m, None) for m in per_symbol)
+
+
 def _host_buffer(nbytes: int):
     """-> (torch uint8 tensor, numpy view of it); page-locked when it is big enough to be worth it"""
     import torch
@@ -144,7 +153,7 @@ class BatchedStreamEncoderMixin:
     def encode(self, data_stream, block_size: int, encode_writer):
         if not hasattr(encode_writer, "write_framed_bytes"):
             return super().encode(data_stream, block_size, encode_writer)  # any writer with write_block
-        if hasattr(data_stream, "read_codes") and hasattr(data_stream, "symbol_of"):
+        if hasattr(data_stream, "symbol_of") and _bulk_capable(data_stream, "read_codes", ("get_block", "get_symbol")):
             return self._encode_bulk(data_stream, block_size, encode_writer)
         per_batch = max(1, MAX_BATCH_BYTES // max(1, block_size))
         while True:
@@ -522,7 +531,8 @@ class BatchedStreamDecoderMixin:
         is not one it can write in bulk) -> (device table, whether it is the identity, numpy dtype of the codes)"""
         import torch
 
-        if not (hasattr(output_stream, "write_codes") and hasattr(output_stream, "code_of")):
+        if not (hasattr(output_stream, "code_of") and
+                _bulk_capable(output_stream, "write_codes", ("write_block", "write_symbol"))):
             return None
         key = (type(output_stream), id(alphabet))
         cache = self.__dict__.setdefault("_code_tables", {})

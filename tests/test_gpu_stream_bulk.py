@@ -251,3 +251,35 @@ def test_random_stream_campaign(seed, tmp_path, monkeypatch):
     with EncodedBlockReader(a) as r:
         dec.decode(r, lst)
     assert lst.input_list == data.tolist()
+
+
+def test_subclassed_streams_keep_the_list_shape(tmp_path):
+    """a stream class that overrides the per-symbol / per-block methods (here: counting, and mapping on the way out) must
+    see every symbol: no bulk shortcut around it"""
+    backend_lib.require_device()
+
+    class Counting(Uint8FileDataStream):
+        seen = 0
+
+        def get_block(self, block_size):
+            blk = super().get_block(block_size)
+            if blk is not None:
+                Counting.seen += blk.size
+            return blk
+
+    class Upper(Uint8FileDataStream):
+        def write_block(self, data_block):
+            super().write_block(DataBlock([s ^ 0x20 for s in data_block.data_list]))
+
+    rng = np.random.default_rng(3)
+    data = rng.choice(np.arange(97, 123), size=5_000).astype(np.uint8)
+    fr = Frequencies({int(c): 2 if c != 97 else 14 for c in range(97, 123)})   # total 64: a power of two for every coder
+    enc, dec = _coders("rans", fr)
+    src, a, out = (os.path.join(tmp_path, x) for x in ("in.bin", "a.bin", "out.bin"))
+    data.tofile(src)
+    with Counting(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 512, w)
+    assert Counting.seen == data.size
+    with EncodedBlockReader(a) as r, Upper(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == bytes(int(b) ^ 0x20 for b in data)
