@@ -74,6 +74,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline only (the default 1-GPU run also measures configs[1..3], see the docstring)")
     ap.add_argument("--gather", action="store_true", help="also time compaction + gather to rank 0")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL record (tens of KB: other_configs, stream_file, every roofline field) as the one "
+                         "line instead of the compact contract line; the full record always goes to --full-json")
+    ap.add_argument("--full-json", default=None,
+                    help="where the full record is written (default: gpurun_out/bench_full.json under the repo root)")
     ap.add_argument("--watchdog-s", type=float, default=None,
                     help="a phase that makes no progress for this long ends the process with exit code 3 and names the "
                          "phase (default: 600 s for --gpus > 1, off otherwise)")
@@ -323,8 +328,8 @@ def restatement_baseline(w, spec, sym_dev, enc):
 
     import scl_restatement as rst
 
-    # bounded: <= 32 workers x `per` chunks (a 4 KiB chunk takes 0.2 - 3 s per direction pair in pure Python)
-    cores = min(len(os.sched_getaffinity(0)), 32)
+    # bounded: one worker per host core x `per` chunks (a 4 KiB chunk takes 0.2 - 3 s per direction pair in pure Python)
+    cores = len(os.sched_getaffinity(0))
     slow = w.coder == "aec" and (spec.get("model") != "orderk" or spec.get("K", 0) > 64)
     per = (1 if slow else 4) if w.chunk_len <= 4096 else 1
     n = min(sym_dev.shape[0], cores * per)
@@ -723,6 +728,78 @@ def summary_entry(r_enc, r_dec, r_dense, cpu, rst):
             "cpu_c": round(cpu["value"], 1) if cpu else None, "cpu_py": round(rst["value"], 3) if rst else None}
 
 
+LINE_LIMIT = 6144  # bytes: the driver's record must be able to hold and parse the whole line (round 5's 21.6 KB did not)
+
+
+def write_full_record(out, path=None):
+    """the full record (every roofline field, other_configs, stream_file ...) goes to a FILE, never to stdout / stderr: the
+    driver keeps a bounded tail of both and parses the one line out of it.  Returns the repo-relative path or None."""
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(json.dumps(out) + "\n")
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
+def _compact_roof(r):
+    if not r:
+        return None
+    keep = ("bound", "kernel", "kernels", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+            "read_only_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "after_decode_ms", "encode_ms", "compact_ms")
+    c = {k: r[k] for k in keep if k in r and r[k] is not None or k == "traffic" and k in r}
+    if r.get("traffic") is not None:
+        c["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc, same csrc_sha)"
+    return c
+
+
+def _compact_cpu(c):
+    if not c:
+        return None
+    keep = ("value", "unit", "cores", "kind", "single_thread_MBps", "encode_MBps", "decode_MBps")
+    o = {k: c[k] for k in keep if k in c}
+    o["sample"] = c.get("sample", "")[:200]
+    checked = c.get("gpu_streams_checked_against_oracle", c.get("gpu_streams_checked_against_restatement"))
+    if checked is not None:
+        o["gpu_streams_checked"] = checked
+    return o
+
+
+def compact_line(out, full_path=None):
+    """the ONE line of the contract, < LINE_LIMIT bytes: the contract keys, the rooflines (dominant kernel, encode, decode,
+    dense) with their PMC traffic, both CPU baselines, multi_gpu / gather when present and `summary` (one short entry per
+    BASELINE configuration) as the LAST key.  Everything else is in the full record (`full_record`)."""
+    keys = ("metric", "value", "value_definition", "value_dense", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "encode_MBps", "decode_MBps")
+    line = {k: out[k] for k in keys if k in out}
+    line["roofline"] = _compact_roof(out.get("roofline"))
+    for k in ("roofline_encode", "roofline_decode", "roofline_dense"):
+        line[k] = _compact_roof(out.get(k))
+    line["round_trip_verified"] = out.get("round_trip_verified")
+    line["csrc_sha"] = out.get("csrc_sha")
+    if "multi_gpu" in out:
+        line["multi_gpu"] = out["multi_gpu"]
+    if "gather" in out:
+        g = dict(out["gather"])
+        g["verified"] = bool(g.get("verified"))  # the sentence is in the full record
+        for k in ("per_rank_encode_ms", "per_rank_compact_ms"):
+            g.pop(k, None)
+        line["gather"] = g
+    line["cpu_baseline"] = _compact_cpu(out.get("cpu_baseline"))
+    if "cpu_baseline_restatement" in out:
+        line["cpu_baseline_restatement"] = _compact_cpu(out["cpu_baseline_restatement"])
+    line["full_record"] = full_path
+    line["summary"] = out.get("summary")
+    # never exceed the limit: shed the optional objects, least important first (summary carries their numbers anyway)
+    for k in ("roofline_encode", "roofline_decode", "cpu_baseline_restatement", "roofline_dense", "gather"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
 def other_workloads(args):
     """BASELINE.json's other single-GPU configurations, as (name, flags, steps)"""
     def wl(**kw):
@@ -983,6 +1060,9 @@ def main():
             else:
                 summ[tag] = {"error": o.get("error", "?")[:60]}
         out["summary"] = summ
+        full_path = write_full_record(out, args.full_json)
+        if not args.full_line:
+            out = compact_line(out, full_path)
         # the ONE line of the contract -- at the start of a line of its own even if a library (RCCL prints warnings and its
         # version banner to stdout without a trailing newline) left the cursor elsewhere
         sys.stdout.flush()

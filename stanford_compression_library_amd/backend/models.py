@@ -10,6 +10,7 @@ Everything raises ``SclHipError`` when the HIP library or a device is missing: n
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -118,21 +119,29 @@ class _DeviceModel:
         return out[: (nbits.value + 7) // 8], int(nbits.value)
 
     # decode_host sizes its host output from the stream's OWN size header: a damaged or hostile block can ask for up to
-    # 2^32 symbols (a symbol can cost 0 bits, so the stream length is no bound).  Callers cap it: above ``max_block_size``
-    # the call raises the AssertionError the size check in ``encode_block`` raises (drop-in classes: same exception type
-    # as the reference's ``assert data_block.size < (1 << DATA_BLOCK_SIZE_BITS)``), before anything is allocated.
-    DEFAULT_MAX_BLOCK_SIZE = 1 << 24
+    # 2^32 symbols (a symbol can cost 0 bits, so the stream length is no bound).  The DEFAULT accepts whatever the
+    # reference's default header (DATA_BLOCK_SIZE_BITS = 32) can announce -- reference parity: ``encode_block`` ->
+    # ``decode_block`` of any block the reference codes must decode here too (a 2^24 default refused valid
+    # blocks and broke the file decoder's one-block path).  A caller reading untrusted streams sets ``max_block_size`` on
+    # the decoder (opt-in): above it the call raises the AssertionError the size check in ``encode_block`` raises (same
+    # exception type as the reference's ``assert data_block.size < (1 << DATA_BLOCK_SIZE_BITS)``), before anything is
+    # allocated.  Raised explicitly, not with ``assert``: ``python -O`` must not remove the guard.
+    DEFAULT_MAX_BLOCK_SIZE = (1 << 32) - 1
+
+    def _check_block_size(self, n: int, max_block_size: Optional[int]):
+        cap = self.DEFAULT_MAX_BLOCK_SIZE if max_block_size is None else int(max_block_size)
+        if int(n) > cap:
+            raise AssertionError(f"encoded block announces {n} symbols, more than max_block_size = {cap} "
+                                 "(damaged stream? set max_block_size to decode larger blocks)")
 
     def decode_host(self, packed: np.ndarray, nbits: int, size_bits: int, max_block_size: Optional[int] = None):
         """(packed bytes, available bits) -> (index array of ``sym_dtype``, num_bits_consumed).  ``max_block_size``
-        (default ``DEFAULT_MAX_BLOCK_SIZE`` = 2^24 symbols): largest block size the header may announce."""
+        (default ``DEFAULT_MAX_BLOCK_SIZE`` = 2^32 - 1 symbols): largest block size the header may announce."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
-        cap = self.DEFAULT_MAX_BLOCK_SIZE if max_block_size is None else int(max_block_size)
-        assert int(n.value) <= cap, (f"encoded block announces {n.value} symbols, more than max_block_size = {cap} "
-                                     "(damaged stream? pass max_block_size to decode larger blocks)")
+        self._check_block_size(n.value, max_block_size)
         out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
         rc = self._sym_fn("decode_host")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out), int(n.value),
@@ -382,9 +391,7 @@ class AecModel(_DeviceModel):
         n = C.c_uint64(0)
         rc = self._L.scl_stream_block_size_host(_lib.u8_ptr(packed), int(nbits), int(size_bits), C.byref(n))
         _lib.check(rc, "scl_stream_block_size_host")
-        cap = self.DEFAULT_MAX_BLOCK_SIZE if max_block_size is None else int(max_block_size)
-        assert int(n.value) <= cap, (f"encoded block announces {n.value} symbols, more than max_block_size = {cap} "
-                                     "(damaged stream? pass max_block_size to decode larger blocks)")
+        self._check_block_size(n.value, max_block_size)
         out = np.zeros(max(int(n.value), 1), dtype=self.sym_dtype)
         n_out, used = C.c_uint64(0), C.c_uint64(0)
         rc = self._sym_fn("decode_host_resume")(self._h, _lib.u8_ptr(packed), int(nbits), self._host_ptr(out),
@@ -520,27 +527,46 @@ def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     return out, offsets
 
 
-def framed_index_host(buf: np.ndarray, size_bits: int, max_records: Optional[int] = None):
+_index_cache = threading.local()  # framed_index_host's three index arrays, reused from slab to slab (per thread)
+
+
+def _index_arrays(cap: int):
+    have = getattr(_index_cache, "arrays", None)
+    if have is None or have[0].size < cap:
+        have = tuple(np.empty(cap, dtype=np.uint64) for _ in range(3))
+        _index_cache.arrays = have
+    return have
+
+
+def framed_index_host(buf: np.ndarray, size_bits: int, max_records: Optional[int] = None, partial: bool = False):
     """Index of a framed block file held in host memory (``scl_framed_index_host``: the walk
     ``EncodedBlockReader.get_block`` + ``Padder.remove_byte_padding`` make one record at a time, encoded_stream.py:196-225,
     :48-58) -> (bit_offset uint64[n], nbits uint64[n], block_size uint64[n], consumed_bytes).  ``buf`` is a contiguous
     uint8 array; records that cross its end are left for the caller (``consumed_bytes`` says where they start).  A
-    malformed record raises ``AssertionError`` -- the exception the reference's reader asserts with."""
+    malformed record raises ``AssertionError`` -- the exception the reference's reader asserts with; with ``partial`` the
+    call returns a fifth element instead: ``None``, or the message of that error, the four others then describing the
+    valid records IN FRONT of the malformed one (the reference decodes and writes those before it raises).
+
+    The index arrays (worst case one record per 5 bytes: 4.8 x the buffer) are kept per thread and reused; what is
+    returned are copies of the used part."""
     assert buf.dtype == np.uint8 and buf.ndim == 1 and buf.flags.c_contiguous
     L = _lib.load()
     # a record is at least 5 bytes (4-byte size + one payload byte)
     cap = int(buf.size // 5 + 1 if max_records is None else max_records)
-    offs = np.empty(cap, dtype=np.uint64)
-    nbits = np.empty(cap, dtype=np.uint64)
-    sizes = np.empty(cap, dtype=np.uint64)
+    offs, nbits, sizes = _index_arrays(cap)
     n, used = C.c_uint64(0), C.c_uint64(0)
     rc = L.scl_framed_index_host(buf.ctypes.data if buf.size else None, buf.size, int(size_bits), cap,
                                  offs.ctypes.data, nbits.ctypes.data, sizes.ctypes.data, C.byref(n), C.byref(used))
+    err = None
     if rc == _lib.E_PARAM:
-        raise AssertionError(_lib.last_error())
-    _lib.check(rc, "scl_framed_index_host")
+        err = _lib.last_error()
+        if not partial:
+            raise AssertionError(err)
+    else:
+        _lib.check(rc, "scl_framed_index_host")
     k = int(n.value)
-    return offs[:k], nbits[:k], sizes[:k], int(used.value)
+    out = (offs[:k].copy(), nbits[:k].copy(), sizes[:k].copy(), int(used.value))
+    return out + (err,) if partial else out
 
 
 class DensePipeline:

@@ -33,6 +33,12 @@ import numpy as np
 
 from ..backend.models import compact, compact_capacity, compact_into, compact_scratch_bytes, framed_index_host
 
+def _stock_read_codes(data_stream) -> bool:
+    from ..core.data_stream import Uint8FileDataStream
+
+    return getattr(type(data_stream), "read_codes", None) is Uint8FileDataStream.read_codes
+
+
 MAX_BATCH_BYTES = 1 << 28     # symbols per launch: bounds host + device memory whatever the stream length
 MAX_BLOCK_SYMBOLS = 1 << 26   # blocks announcing more symbols than this are decoded one by one (decode_block)
 SLAB_BYTES = 1 << 26          # bulk shape: symbols (encode) / file bytes (decode) per pipeline stage
@@ -178,7 +184,13 @@ class BatchedStreamEncoderMixin:
         lens = np.zeros(n, dtype=np.int32)
         for i, blk in enumerate(blocks):
             data = blk.data_list
-            sym[i, :len(data)] = np.fromiter((index_of[s] for s in data), dtype=model.sym_dtype, count=len(data))
+            try:
+                sym[i, :len(data)] = np.fromiter((index_of[s] for s in data), dtype=model.sym_dtype, count=len(data))
+            except KeyError:
+                # the reference's loop has written blocks 0 .. i-1 when encode_block(block i) raises: so do we
+                if i:
+                    self._encode_batch(blocks[:i], block_size, encode_writer)
+                raise
             lens[i] = len(data)
         dev = torch.device("cuda", torch.cuda.current_device())
         enc = model.encode_batch(torch.from_numpy(sym).to(dev)[:, :block_size] if width == block_size
@@ -212,7 +224,12 @@ class BatchedStreamEncoderMixin:
         per_slab = max(1, min(SLAB_BYTES, MAX_BATCH_BYTES) // block_size)
         n_sym = per_slab * block_size
         fobj = getattr(data_stream, "file_obj", None)
-        byte_file = fobj is not None and "b" in getattr(fobj, "mode", "") and hasattr(fobj, "readinto")
+        # straight-into-the-staging-buffer reads only for a plain binary file behind the stock Uint8FileDataStream: a file
+        # object whose ``mode`` is not a string (gzip.GzipFile: 1 / 2) or a subclass with its own ``read_codes`` goes through
+        # ``read_codes`` like any other stream
+        mode = getattr(fobj, "mode", "")
+        byte_file = (fobj is not None and isinstance(mode, str) and "b" in mode and hasattr(fobj, "readinto")
+                     and _stock_read_codes(data_stream))
         sized = byte_file and _bytes_left(fobj) is not None  # small files: small staging buffers
 
         def new_stage_for_rest():
@@ -230,7 +247,7 @@ class BatchedStreamEncoderMixin:
                 return (stage.h_in[:n] if n else None), True
             return _read_full(data_stream.read_codes, n_sym), False
 
-        stages, lut8, turn, pending = [None, None], None, 0, None
+        stages, lut8, turn, pending, fail = [None, None], None, 0, None, None
         if sized:
             stages[0] = new_stage_for_rest()
         fut = rd.submit(read_slab, stages[0])
@@ -253,6 +270,10 @@ class BatchedStreamEncoderMixin:
                     other.h2d_done.synchronize()  # (long over: its launch was a whole slab ago)
                 fut = rd.submit(read_slab, other)
             # ---- symbols -> alphabet indices on the device ----------------------------------------------------
+            # a symbol the model does not know: the reference's block loop has written every block in front of the
+            # offending one when its encode_block raises KeyError -- so the whole blocks in front of it in this slab are
+            # still encoded and written (with the pending slab) before the KeyError leaves
+            fail = None
             if codes.dtype == np.uint8:
                 if lut8 is None:
                     lut8 = self._code_lut8(data_stream, index_of, model, dev)
@@ -271,34 +292,43 @@ class BatchedStreamEncoderMixin:
                     wide_idx = lut_dev[d_raw[:n].to(torch.int64)]
                     bad = (wide_idx < 0).nonzero()
                     if bad.numel():  # the first symbol the model does not know, as the per-block loop would meet it
-                        raise KeyError(data_stream.symbol_of(int(stage.h_in[int(bad[0].item())])))
-                    d_idx = torch.zeros(nb * block_size, dtype=self._torch_sym_dtype(model), device=dev)
+                        first = int(bad[0].item())
+                        fail = KeyError(data_stream.symbol_of(int(stage.h_in[first])))
+                        nb = first // block_size
+                        n = nb * block_size
+                        wide_idx = wide_idx[:n]
+                    d_idx = torch.zeros(max(nb, 1) * block_size, dtype=self._torch_sym_dtype(model), device=dev)
                     d_idx[:n] = wide_idx.to(d_idx.dtype)
             else:  # code points beyond a byte (rare): mapped on the host through the codes that occur
                 uniq, inv = np.unique(codes, return_inverse=True)
                 vals = np.array([index_of.get(data_stream.symbol_of(int(u)), -1) for u in uniq], dtype=np.int64)
+                mapped = vals[inv]
                 if (vals < 0).any():
-                    first = int(np.flatnonzero(vals[inv] < 0)[0])
-                    raise KeyError(data_stream.symbol_of(int(codes[first])))
-                h_idx = np.zeros(nb * block_size, dtype=model.sym_dtype)
-                h_idx[:n] = vals[inv]
+                    first = int(np.flatnonzero(mapped < 0)[0])
+                    fail = KeyError(data_stream.symbol_of(int(codes[first])))
+                    nb = first // block_size
+                    n = nb * block_size
+                    mapped = mapped[:n]
+                h_idx = np.zeros(max(nb, 1) * block_size, dtype=model.sym_dtype)
+                h_idx[:n] = mapped
                 d_idx = torch.from_numpy(h_idx.view(np.int16) if h_idx.dtype == np.uint16 else h_idx).to(dev)
-            lens = torch.full((nb,), block_size, dtype=torch.int32, device=dev)
-            if n < nb * block_size:
-                lens[-1] = n - (nb - 1) * block_size
-            enc = stage.enc if nb == stage.n_blocks else model.alloc_encoded(nb, block_size, dev,
-                                                                             model.slot_bytes(block_size))
-            model.encode_batch(d_idx.view(nb, block_size), lens=lens, out=enc)
-            d_offs = stage.d_offs[: nb + 1]
-            compact_into(enc, stage.d_framed, d_offs, stage.d_scratch, framed=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            stage.busy = (ev, nb, enc, d_offs)
+            if nb:
+                lens = torch.full((nb,), block_size, dtype=torch.int32, device=dev)
+                if n < nb * block_size:
+                    lens[-1] = n - (nb - 1) * block_size
+                enc = stage.enc if nb == stage.n_blocks else model.alloc_encoded(nb, block_size, dev,
+                                                                                 model.slot_bytes(block_size))
+                model.encode_batch(d_idx[: nb * block_size].view(nb, block_size), lens=lens, out=enc)
+                d_offs = stage.d_offs[: nb + 1]
+                compact_into(enc, stage.d_framed, d_offs, stage.d_scratch, framed=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                stage.busy = (ev, nb, enc, d_offs)
             if pending is not None:  # the previous slab's bytes leave while this one is on the device
                 self._finish_encode_stage(pending, encode_writer, wr)
-            pending = stage
+            pending = stage if nb else None
             turn ^= 1
-            if last:
+            if last or fail is not None:
                 break
         if pending is not None:
             self._finish_encode_stage(pending, encode_writer, wr)
@@ -306,6 +336,8 @@ class BatchedStreamEncoderMixin:
             if st is not None and st.written is not None:
                 st.written.result()  # (re-raises what the writer thread met)
                 st.written = None
+        if fail is not None:
+            raise fail
 
     @staticmethod
     def _torch_sym_dtype(model):
@@ -409,7 +441,14 @@ class BatchedStreamDecoderMixin:
             if filled == 0:
                 return
             h_t, h = bufs[turn]
-            offs, nbits, sizes, used = framed_index_host(h[:filled], sb)
+            offs, nbits, sizes, used, bad = framed_index_host(h[:filled], sb, partial=True)
+            if bad is not None:
+                # a malformed record: the reference's block loop has decoded and written every record in front of it by the
+                # time it raises (data_encoder_decoder.py:118-144) -- so do that first
+                if len(offs):
+                    self._decode_slab(h_t, h, used, offs, nbits, sizes, sink)
+                sink.drain()
+                raise AssertionError(bad)
             if len(offs) == 0:
                 _check(not eof, "truncated block file")
                 # one record larger than the staging buffer: make room for it (header says how much) and read on

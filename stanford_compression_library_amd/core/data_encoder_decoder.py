@@ -45,7 +45,8 @@ class DataEncoder(abc.ABC):
 
 class DataDecoder(abc.ABC):
     # Largest block size a size header may announce to ``decode_block`` of the HIP-backed decoders before they allocate
-    # the output (None: the backend's default, 2^24 symbols).  A symbol can cost 0 bits, so the stream's length is no
+    # the output (None: the backend's default, 2^32 - 1 = whatever the reference's 32-bit header can announce; set it
+    # when reading untrusted streams).  A symbol can cost 0 bits, so the stream's length is no
     # bound; a damaged header above this raises AssertionError -- the exception the encoder's own size check raises.
     # No reference counterpart (the reference decodes symbol by symbol into a Python list).
     max_block_size = None

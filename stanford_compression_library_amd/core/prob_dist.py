@@ -18,13 +18,19 @@ class ProbabilityDist:
     """Ordered symbol -> probability map (reference scl/core/prob_dist.py:6-90)."""
 
     def __init__(self, prob_dict: Dict[Hashable, float] = None):
+        self._validate_prob_dist(prob_dict)
+        self.prob_dict = prob_dict
+
+    @staticmethod
+    def _validate_prob_dist(prob_dict) -> None:
+        """every probability at least 1e-6 (AssertionError) and the sum within 1e-8 of one (ValueError) -- the checks and
+        the exception types of reference scl/core/prob_dist.py:77-90"""
         total = 0.0
         for p in prob_dict.values():
             assert p >= 1e-6, "probabilities negative or too small cause stability issues"
             total += p
         if abs(total - 1.0) > 1e-8:
             raise ValueError("probabilities do not sum to 1")
-        self.prob_dict = prob_dict
 
     def __repr__(self):
         return f"ProbabilityDist({self.prob_dict!r})"

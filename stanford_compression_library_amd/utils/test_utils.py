@@ -8,16 +8,21 @@ this package's own.
 """
 from __future__ import annotations
 
+import filecmp
+import os
+import tempfile
 from typing import Tuple
 
 import numpy as np
 
 from ..core.data_block import DataBlock
 from ..core.data_encoder_decoder import DataDecoder, DataEncoder
+from ..core.data_stream import TextFileDataStream, Uint8FileDataStream
 from ..core.prob_dist import Frequencies, ProbabilityDist, get_avg_neg_log_prob
 from .bitarray_utils import BitArray, get_random_bitarray
 
-__all__ = ["get_random_data_block", "are_blocks_equal", "try_lossless_compression", "lossless_entropy_coder_test",
+__all__ = ["get_random_data_block", "create_random_text_file", "create_random_binary_file", "are_blocks_equal",
+           "try_lossless_compression", "try_file_lossless_compression", "lossless_entropy_coder_test",
            "lossless_test_against_expected_bitrate"]
 
 _MAX_TRAILING_BITS = 100  # the reference appends np.random.randint(100) random bits (test_utils.py:98-101)
@@ -28,6 +33,18 @@ def get_random_data_block(prob_dist: ProbabilityDist, size: int, seed: int = Non
     same block for the same seed -- the golden vectors rely on it."""
     symbols = np.random.default_rng(seed).choice(prob_dist.alphabet, size=size, p=prob_dist.prob_list)
     return DataBlock(symbols.tolist())
+
+
+def create_random_text_file(file_path: str, file_size: int, prob_dist: ProbabilityDist) -> None:
+    """``file_size`` i.i.d. characters from ``prob_dist`` written as a text file (reference :31-41; unseeded, like there)"""
+    with TextFileDataStream(file_path, "w") as fds:
+        fds.write_block(get_random_data_block(prob_dist, file_size))
+
+
+def create_random_binary_file(file_path: str, file_size: int, prob_dist: ProbabilityDist) -> None:
+    """the same for a binary file: the distribution's alphabet must be byte values 0..255 (reference :44-55)"""
+    with Uint8FileDataStream(file_path, "wb") as fds:
+        fds.write_block(get_random_data_block(prob_dist, file_size))
 
 
 def are_blocks_equal(data_block_1: DataBlock, data_block_2: DataBlock) -> bool:
@@ -55,6 +72,18 @@ def try_lossless_compression(data_block: DataBlock, encoder: DataEncoder, decode
         print(f"{data_block.size} symbols -> {len(code)} bits (+{len(fed) - len(code)} trailing), consumed {consumed}")
     assert consumed == len(code), "Decoder did not consume all bits"
     return are_blocks_equal(data_block, back), consumed, code
+
+
+def try_file_lossless_compression(input_file_path: str, encoder: DataEncoder, decoder: DataDecoder,
+                                  encode_block_size=1000) -> bool:
+    """``encode_file`` into a temporary directory, ``decode_file`` back, compare the bytes with the input (reference
+    :111-135).  Text files, like there: ``encode_file`` / ``decode_file`` open text streams (data_encoder_decoder.py:71-83,
+    :146-158).  With the HIP-backed coders this is the streaming driver's path end to end (row f2)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        coded, back = os.path.join(tmp, "encoded_file.bin"), os.path.join(tmp, "reconst_file.txt")
+        encoder.encode_file(input_file_path, coded, block_size=encode_block_size)
+        decoder.decode_file(coded, back)
+        return filecmp.cmp(input_file_path, back, shallow=False)
 
 
 def lossless_entropy_coder_test(encoder: DataEncoder, decoder: DataDecoder, freq: Frequencies, data_size: int,

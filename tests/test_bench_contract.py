@@ -90,3 +90,68 @@ def test_default_line_contract(name):
     assert abs(s["headline"]["f_dense"] - line["roofline_dense"]["frac"]) < 1e-3
     d = line["roofline_dense"]
     assert d["traffic"] is None or d["traffic"] > 1.8 * d["algorithmic_bytes_per_launch"]  # two transfers more than algorithmic
+
+
+# ---- round 6: the line the driver records (a 21.6 KB line left BENCH_r05.json unparsed) -------------------
+def _import_bench():
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+FULL_RECORDS = sorted(glob.glob(os.path.join(PROF, "r0[5-9]_bench_driver_style*.json")) +
+                      glob.glob(os.path.join(PROF, "r0[5-9]_bench_headline_full.json")) +
+                      glob.glob(os.path.join(PROF, "r0[6-9]_bench_full*.json")))
+
+
+@pytest.mark.parametrize("path", FULL_RECORDS, ids=[os.path.basename(p) for p in FULL_RECORDS])
+def test_compact_line_is_small_and_carries_the_contract(path):
+    bench = _import_bench()
+    full = _line(path)
+    if "other_configs" not in full and "full_record" in full:
+        pytest.skip("already a compact line")
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT == 6144, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
+        assert k in back, k
+    assert list(back)[-1] == "summary"
+    r = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    c = back["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert "other_configs" not in back and "stream_file" not in back
+    assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"]
+
+
+COMPACT_LINES = sorted(glob.glob(os.path.join(PROF, "r0[6-9]_bench_line*.json")))
+
+
+@pytest.mark.parametrize("path", COMPACT_LINES, ids=[os.path.basename(p) for p in COMPACT_LINES])
+def test_committed_driver_line_parses_and_is_small(path):
+    """the bytes bench.py printed on the GPU box, as the driver sees them"""
+    raw = [ln for ln in open(path) if ln.startswith("{")]
+    assert len(raw) == 1
+    assert len(raw[0]) < 6144
+    line = json.loads(raw[0])
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0 and list(line)[-1] == "summary"
+
+
+def test_compact_line_survives_an_oversized_record():
+    """whatever the full record grows to, the printed line sheds optional objects until it fits"""
+    bench = _import_bench()
+    full = _line(FULL_RECORDS[0])
+    full["cpu_baseline"]["sample"] = "x" * 5000
+    full["config"]["workload"] = "w" * 3000
+    for k in ("roofline_encode", "roofline_decode", "roofline_dense"):
+        full[k]["kernel"] = "k" * 800
+    line = bench.compact_line(full, None)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert "roofline" in line and "cpu_baseline" in line and "summary" in line

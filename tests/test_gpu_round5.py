@@ -137,8 +137,12 @@ def test_decode_block_refuses_oversized_header(dev):
     dec = rANSDecoder(params)
     block, used = dec.decode_block(bits)
     assert block.data_list == list("ABBB" * 50) and used == len(bits)
-    # the same stream with a header announcing 2^31 symbols: refused before any allocation, as an AssertionError
+    # the same stream with a header announcing 2^31 symbols, read by a decoder that opted into a cap (untrusted input):
+    # refused before any allocation, as an AssertionError.  (The default accepts what a 32-bit header can announce --
+    # reference parity)
     lie = uint_to_bitarray(1 << 31, 32) + bits[32:]
+    assert dec.max_block_size is None and dec.params._device_model().DEFAULT_MAX_BLOCK_SIZE == (1 << 32) - 1
+    dec.max_block_size = 1 << 24
     with pytest.raises(AssertionError, match="max_block_size"):
         dec.decode_block(lie)
     # a caller that really has large blocks raises the cap; a small cap refuses an honest block

@@ -99,6 +99,16 @@ def test_sparse_alphabet_lut_and_unknown_symbol(tmp_path):
     with pytest.raises(KeyError) as e2, EncodedBlockWriter(b) as w:
         enc.encode(ListDataStream(bad.tolist()), 1000, w)
     assert e2.value.args == e.value.args
+    # ... and, like the reference's block loop, every block in front of the offending one (block 4) has been written by
+    # then: both shapes leave the first four records of the good file behind, whatever the slab size
+    good = _encode_list(enc, data[:4000].tolist(), 1000, os.path.join(tmp_path, "g.bin"))
+    assert open(a, "rb").read() == good and open(b, "rb").read() == good
+    for slab in (1000, 3000, 5000):
+        with pytest.MonkeyPatch.context() as mp:
+            mp.setattr(_stream_batch, "SLAB_BYTES", slab)
+            with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w, pytest.raises(KeyError):
+                enc.encode(s, 1000, w)
+        assert open(a, "rb").read() == good, slab
 
 
 @pytest.mark.parametrize("alphabet", ["abcdefgh \n", "abéÿ \n", "abλ中 \n"])
@@ -283,3 +293,98 @@ def test_subclassed_streams_keep_the_list_shape(tmp_path):
     with EncodedBlockReader(a) as r, Upper(out, "wb") as s:
         dec.decode(r, s)
     assert open(out, "rb").read() == bytes(int(b) ^ 0x20 for b in data)
+
+
+def test_malformed_record_after_valid_ones_decodes_them_first(tmp_path):
+    """the reference's reader raises at the malformed record, after the records in front of it were decoded and written"""
+    backend_lib.require_device()
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 4, size=6000, dtype=np.uint8)
+    enc, dec = _coders("rans", Frequencies({0: 5, 1: 1, 2: 1, 3: 1}))
+    src, a, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "out.bin"))
+    data.tofile(src)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 1000, w)
+    blob = bytearray(open(a, "rb").read())
+    # walk to record 3 and make its payload shorter than a size header (a 1-byte payload, 8 - pad - 3 bits of it)
+    pos = 0
+    for _ in range(3):
+        pos += 4 + int.from_bytes(blob[pos:pos + 4], "big")
+    bad = bytes(blob[:pos]) + (1).to_bytes(4, "big") + b"\x00" + bytes(blob[pos:])
+    open(a, "wb").write(bad)
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s, pytest.raises(AssertionError):
+        dec.decode(r, s)
+    assert open(out, "rb").read() == data[:3000].tobytes()
+
+
+def test_gzip_like_file_object_and_read_codes_override(tmp_path):
+    """a file object whose ``mode`` is not a string (gzip.GzipFile: an int) and a stream subclass that overrides
+    only ``read_codes`` both go through ``read_codes``, not the direct ``readinto`` path"""
+    import gzip
+
+    backend_lib.require_device()
+    rng = np.random.default_rng(4)
+    data = rng.integers(0, 4, size=5000, dtype=np.uint8)
+    enc, dec = _coders("rans", Frequencies({0: 5, 1: 1, 2: 1, 3: 1}))
+    src, gz, a, b = (os.path.join(tmp_path, n) for n in ("in.bin", "in.gz", "a.bin", "b.bin"))
+    data.tofile(src)
+    with gzip.open(gz, "wb") as f:
+        f.write(data.tobytes())
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 777, w)
+    s = Uint8FileDataStream(src, "rb")
+    s.__enter__()
+    s.file_obj.close()
+    s.file_obj = gzip.GzipFile(gz, "rb")
+    assert not isinstance(s.file_obj.mode, str)
+    with EncodedBlockWriter(b) as w:
+        enc.encode(s, 777, w)
+    s.file_obj.close()
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+    class Inverted(Uint8FileDataStream):  # only read_codes overridden: its view of the file must be what gets encoded
+        def read_codes(self, n):
+            c = super().read_codes(n)
+            return None if c is None else (3 - c).astype(np.uint8)
+
+    with Inverted(src, "rb") as s, EncodedBlockWriter(b) as w:
+        enc.encode(s, 777, w)
+    out = ListDataStream([])
+    with EncodedBlockReader(b) as r:
+        dec.decode(r, out)
+    assert out.input_list == (3 - data).tolist()
+
+
+def test_blocks_above_16Mi_symbols_decode_by_default(tmp_path, monkeypatch):
+    """a 2^24 default cap on the size header refused valid blocks -- plain ``encode_block`` ->
+    ``decode_block`` above 16 Mi symbols, and the file decoder's one-block path (blocks above ``MAX_BLOCK_SYMBOLS``).  The
+    default now accepts whatever the reference's 32-bit header announces; ``max_block_size`` is an opt-in guard."""
+    backend_lib.require_device()
+    n = (1 << 24) + 3
+    rng = np.random.default_rng(24)
+    data = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fr = Frequencies({0: 5, 1: 1, 2: 1, 3: 1})
+    enc, dec = _coders("rans", fr)
+    assert dec.max_block_size is None
+    bits = enc.encode_block(DataBlock(data.tolist()))
+    block, used = dec.decode_block(bits)
+    assert used == len(bits) and block.size == n
+    assert np.array_equal(np.asarray(block.data_list, dtype=np.uint8), data)
+    dec.max_block_size = 1 << 24  # opt-in guard: the same block is refused, before anything is allocated
+    with pytest.raises(AssertionError, match="max_block_size"):
+        dec.decode_block(bits)
+    # the file decoder's one-block path with BOTH limits in play: a block above MAX_BLOCK_SYMBOLS is decoded through
+    # decode_block, whose cap is the decoder's own (None = accept)
+    small = data[:5000]
+    a, out = os.path.join(tmp_path, "a.bin"), os.path.join(tmp_path, "out.bin")
+    small.tofile(os.path.join(tmp_path, "in.bin"))
+    with Uint8FileDataStream(os.path.join(tmp_path, "in.bin"), "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 1000, w)
+    monkeypatch.setattr(_stream_batch, "MAX_BLOCK_SYMBOLS", 400)
+    dec.max_block_size = None
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == small.tobytes()
+    dec.max_block_size = 999
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s, pytest.raises(AssertionError, match="max_block_size"):
+        dec.decode(r, s)

@@ -1,6 +1,7 @@
 """Host-side surface of the path (no GPU): BitArray, DataBlock, Frequencies, the params dataclasses and the
 frequency-model mirrors behave like the reference's (values below were produced by the imported reference)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -187,3 +188,26 @@ def test_get_counts_equals_reference_fixture():
         if case.n:
             pd = block.get_empirical_distribution().prob_dict
             assert np.allclose([pd[s] for s in sorted(pd)], case.arr("probs"), rtol=0, atol=1e-15)
+
+
+# ---- file-level harness of the reference (VERDICT r5 missing #4, #5) ---------------------------------------------------------
+def test_random_file_creators_and_prob_dist_validation(tmp_path):
+    """``create_random_text_file`` / ``create_random_binary_file`` (reference utils/test_utils.py:31-55) write ``file_size``
+    symbols of the distribution's alphabet; ``ProbabilityDist._validate_prob_dist`` (core/prob_dist.py:77-90) keeps the
+    reference's two checks and exception types"""
+    from stanford_compression_library_amd.core.prob_dist import ProbabilityDist
+    from stanford_compression_library_amd.utils.test_utils import create_random_binary_file, create_random_text_file
+
+    text = os.path.join(tmp_path, "t.txt")
+    create_random_text_file(text, 5000, ProbabilityDist({"A": 0.5, "B": 0.25, "C": 0.25}))
+    got = open(text).read()
+    assert len(got) == 5000 and set(got) == set("ABC") and 2200 < got.count("A") < 2800
+    binary = os.path.join(tmp_path, "b.bin")
+    create_random_binary_file(binary, 4096, ProbabilityDist({0: 0.5, 7: 0.25, 255: 0.25}))
+    raw = open(binary, "rb").read()
+    assert len(raw) == 4096 and set(raw) == {0, 7, 255}
+    ProbabilityDist._validate_prob_dist({"a": 0.5, "b": 0.5})
+    with pytest.raises(ValueError, match="sum to 1"):
+        ProbabilityDist._validate_prob_dist({"a": 0.5, "b": 0.4})
+    with pytest.raises(AssertionError, match="too small"):
+        ProbabilityDist({"a": 1.0 - 1e-7, "b": 1e-7})

@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$NAME
 RAW=/tmp/prof_raw_$NAME
 rm -rf $RAW $OUT; mkdir -p $OUT $RAW
-python $REPO/bench.py --no-cpu-baseline --no-other-configs ${BENCH_ARGS} 2>/dev/null | grep '^{' > $OUT/bench.json
+python $REPO/bench.py --full-line --no-cpu-baseline --no-other-configs ${BENCH_ARGS} 2>/dev/null | grep '^{' > $OUT/bench.json
 # (--no-dense-pipeline: that measurement launches the encode kernel on half batches; per-kernel means must not mix them in)
 TRACE_CMD="python $REPO/bench.py --no-cpu-baseline --no-other-configs --no-dense-pipeline ${BENCH_ARGS}"
 CMD="python $REPO/bench.py --steps 3 --warmup 1 --min-warm-ms 0 --no-cpu-baseline --no-other-configs --no-dense-pipeline ${BENCH_ARGS}"
