@@ -44,6 +44,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def host_cores():
+    """(cores this process may actually use, logical CPUs it may be scheduled on): the affinity mask, cut down to the
+    cgroup's CPU quota when the container has one (a 256-thread box that grants 64 CPUs' worth of time runs 256 workers
+    slower than 64)"""
+    logical = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    usable = logical if quota is None else max(1, min(logical, int(quota + 0.5)))
+    return usable, logical
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOAD_FLAGS = ("chunks", "chunk_len", "table", "coder", "aec_K", "aec_model", "num_bits_out", "range_factor", "source",
                   "sym_pad")
@@ -267,7 +290,7 @@ def cpu_baseline(w, spec, sym_dev, enc, target_seconds=10.0):
     freq = spec.get("freq")
     chunk_len = int(sym_dev.shape[1])
     # the C oracle runs a slice of chunks per call; ctypes releases the GIL, so one Python thread per host core scales
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores, logical = host_cores()  # every core the container may use
     n_probe = min(32, sym_dev.shape[0])
     sym = sym_dev[:n_probe].cpu().numpy()
     t0 = time.perf_counter()
@@ -311,12 +334,15 @@ def cpu_baseline(w, spec, sym_dev, enc, target_seconds=10.0):
         "kind_note": "C port of the algorithm (oracle/scl_oracle.c), a 'reasonable CPU' line; the reference itself is pure "
                      "Python: see cpu_baseline_restatement for its speed",
         "sample": f"{n} chunks x {chunk_len} B of the same batch ({nbytes / 2**20:.1f} MiB), oracle/scl_oracle.c "
-                  f"-O2, {len(parts)} threads (one per host core), encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode "
+                  f"-O2, {len(parts)} threads (one per usable host core; {logical} logical CPUs), encode {nbytes / (t1 - t0) / 1e6:.2f} MB/s + decode "
                   f"{nbytes / (t2 - t1) / 1e6:.2f} MB/s aggregate; one thread alone: {single_thread:.2f} MB/s round trip",
         "single_thread_MBps": round(single_thread, 3),
         "encode_MBps": round(nbytes / (t1 - t0) / 1e6, 3), "decode_MBps": round(nbytes / (t2 - t1) / 1e6, 3),
         "gpu_streams_checked_against_oracle": checked,
     }
+
+
+RESTATEMENT_MAX_WORKERS = 64
 
 
 def restatement_baseline(w, spec, sym_dev, enc):
@@ -328,8 +354,11 @@ def restatement_baseline(w, spec, sym_dev, enc):
 
     import scl_restatement as rst
 
-    # bounded: one worker per host core x `per` chunks (a 4 KiB chunk takes 0.2 - 3 s per direction pair in pure Python)
-    cores = len(os.sched_getaffinity(0))
+    # bounded: one worker PROCESS per host core x `per` chunks (a 4 KiB chunk takes 0.2 - 3 s per direction pair in pure
+    # Python), at most RESTATEMENT_MAX_WORKERS of them: forking more copies of this process costs more wall time than the
+    # sample they would add (256 workers: 31 s per configuration on the round-6 box) -- the cap is stated in `sample`
+    usable, logical = host_cores()
+    cores = min(usable, RESTATEMENT_MAX_WORKERS)
     slow = w.coder == "aec" and (spec.get("model") != "orderk" or spec.get("K", 0) > 64)
     per = (1 if slow else 4) if w.chunk_len <= 4096 else 1
     n = min(sym_dev.shape[0], cores * per)
@@ -348,7 +377,8 @@ def restatement_baseline(w, spec, sym_dev, enc):
     return {
         "value": round(r["round_trip_MBps_aggregate"], 4), "unit": "MB/s", "cores": r["workers"], "kind": "restatement",
         "sample": f"{r['chunks']} chunks x {sym.shape[1]} B of the same batch, oracle/scl_restatement.py (pure Python, per-symbol, "
-                  f"the reference's algorithmic shape), {r['workers']} worker processes x {per} chunks, wall {r['wall_s']:.1f} s",
+                  f"the reference's algorithmic shape), {r['workers']} worker processes x {per} chunks ({usable} usable cores, {logical} logical CPUs; "
+                  f"at most {RESTATEMENT_MAX_WORKERS} workers), wall {r['wall_s']:.1f} s",
         "per_core_MBps": {"encode": round(r["encode_MBps_per_core"], 5), "decode": round(r["decode_MBps_per_core"], 5),
                           "round_trip": round(r["round_trip_MBps_per_core"], 5)},
         "reference_over_restatement": "0.7-1.25 by coder (BASELINE.md 4.2 / 4.3, measured in the build container against the "

@@ -37,9 +37,6 @@
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
 
-#ifndef AF_ABLATE
-#define AF_ABLATE 0  // timing experiments only (tools/ablate_aec.sh); 0 = the product
-#endif
 #define AF_THREADS 256
 #define AF_CTX_BYTES (AF_THREADS * 32)      // one 32-byte row of every thread
 #define AF_TABLE_BYTES (16 * AF_CTX_BYTES)  // 128 KiB
@@ -257,16 +254,6 @@ __global__ void __launch_bounds__(AF_THREADS)
 // Symbols leave through 64 bytes of LDS per lane (the 16 KiB the totals used to take) as whole 64-byte sectors -- four
 // back-to-back 16-byte stores every 64 symbols -- instead of one 4-byte store per four symbols, which the memory system
 // did not merge at 262 144 open lines: 12.6 GB of HBM writes for 1 GiB of symbols (profiles/traffic.json, round 3).
-#ifndef AD_CD_SPLIT
-#define AD_CD_SPLIT 1  // c and d as two 2-byte LDS reads; 0: one 4-byte read at a 2-byte-aligned address (legal, and what the
-                       // compiler makes of two adjacent reads on its own -- but 3.6 % slower: 5.63 against 5.42 ms)
-#endif
-#ifndef AD_QUADS
-#define AD_QUADS 1  // the unchecked stretches of the decoder in groups of four symbols
-#endif
-#ifndef AD_XT_PLACE
-#define AD_XT_PLACE 1  // 1: 1/T between the search and the wait for c, d; 0: wherever the compiler puts it (the top)
-#endif
 #define AD_ROW_BASE 16                             // rows start 16 bytes in: the address "two bytes before a row" is never negative
 #define AD_OUT_BASE (AD_ROW_BASE + AF_TABLE_BYTES)  // [thread][64 bytes]
 #define AD_OUT_BYTES (AF_THREADS * 64)
@@ -349,15 +336,10 @@ __global__ void __launch_bounds__(AF_THREADS)
         // c = Y[s - 1], d = Y[s]: two u16 reads, issued before the row is rewritten; s = 0 reads the two bytes in front of
         // the row, masked away below.  All addresses of the step hang off "row - 2": one add fewer than with "row" and "- 2".
         const u32 ea_m2 = row_m2 + 2 * s;
-#if AD_CD_SPLIT
         u32 c_raw = *reinterpret_cast<const u16_lds *>(lds + ea_m2);
         u32 ea_d = ea_m2;
         asm("" : "+v"(ea_d));  // hides that the two reads are adjacent (the compiler would merge them into one unaligned read)
         u32 d_raw = *reinterpret_cast<const u16_lds *>(lds + ea_d + 2);
-#else
-        u32 cd;
-        __builtin_memcpy(&cd, lds + ea_m2, 4);
-#endif
         // update_model: Y[j] += 1 for j >= s, i.e. minus the search's masks
         *reinterpret_cast<uint4_lds *>(lds + row_m2 + 2) =
             make_uint4(af_pk_sub(Y[0], msk[0]), af_pk_sub(Y[1], msk[1]), af_pk_sub(Y[2], msk[2]), af_pk_sub(Y[3], msk[3]));
@@ -369,24 +351,12 @@ __global__ void __launch_bounds__(AF_THREADS)
         R = af_row_load(lds, row_m2 + 2);
         // (the empty asm statements around 1/T place its seven instructions after the search and before the wait for c, d)
         float T2 = Tf;
-#if AD_XT_PLACE == 1
         asm volatile("" : "+v"(T2) : "v"(s));
-#endif
         double xT = af_recip_fd(T2, Td);
         asm volatile("" : "+v"(xT));
-#if AD_CD_SPLIT
         asm volatile("" : "+v"(c_raw), "+v"(d_raw));
         const u32 c = c_raw & ~msk[0];
         af_shrink2_d(low, hm, (double)c, (double)d_raw, xT);
-#else
-        asm volatile("" : "+v"(cd));
-        // c = low half, 0 for s = 0 (<=> Y[0] > target <=> the low half of msk[0] is all ones); d = high half, converted
-        // straight out of the pair (d < 2^15: exact as float)
-        const u32 c = cd & 0xFFFFu & ~msk[0];
-        float df;
-        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(df) : "v"(cd));
-        af_shrink2_d(low, hm, (double)c, (double)df, xT);
-#endif
         so.put(s, i);  // four to a word, sixteen words to a 64-byte sector (AfSymOut)
     };
     // ---- renormalisation, :245-275; UNCHECKED selects the reader's refill (AfReader::next_word) ----
@@ -436,7 +406,6 @@ __global__ void __launch_bounds__(AF_THREADS)
         if (cnt == 0xFFFFFFFFu || cnt < 16) break;
         if (at_work) {
             const u32 *before = rd.ptr;
-#if AD_QUADS
             // four symbols per trip once the index is a multiple of four: which byte of the output word a symbol fills, and
             // when the word is complete, are then known at compile time (AfSymOut::put: no scalar compare-and-branch per
             // symbol), and the trip count is tested once per four
@@ -458,12 +427,6 @@ __global__ void __launch_bounds__(AF_THREADS)
                 step(i + u);
                 renorm(std::true_type{});
             }
-#else
-            for (u32 u = 0; u < cnt; ++u) {
-                step(i + u);
-                renorm(std::true_type{});
-            }
-#endif
             rd.settle(before);
         }
         i += cnt;

@@ -6,10 +6,6 @@
 #pragma once
 #include "scl_common.h"
 
-#ifndef AF_ABLATE
-#define AF_ABLATE 0  // timing experiments only (tools/ablate_aec.sh); 0 = the product
-#endif
-
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // LDS rows are read as 2-byte elements and written as 16-byte halves: the accesses must not be reordered by
@@ -94,11 +90,7 @@ struct AfWriterT {
         if (tot >= 32) {
             const u32 r = tot - 32;  // <= 31; nb - r = 32 - nacc
             const u32 word = (r == 0) ? ((hi << (nb & 31)) | v) : ((hi << (nb - r)) | (v >> r));
-#if AF_ABLATE == 1
-            nwords++;
-#else
             emit(__builtin_bswap32(word));
-#endif
             hi = v & ((1u << r) - 1u);
             nacc = r;
         } else {

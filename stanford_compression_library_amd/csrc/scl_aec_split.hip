@@ -38,9 +38,7 @@
 #include "scl_aec_math.h"
 #include "scl_aec_lane_io.h"
 
-#ifndef AS_LANES
 #define AS_LANES 64                    // chunks per workgroup: one wave per role, four workgroups per CU (40 KiB of LDS each)
-#endif
 #define AS_THREADS (3 * AS_LANES)      // wave 0: model role, wave 1: coder role, wave 2: writer role
 #define AS_PLANE (AS_LANES * 4)        // one u32 of every chunk
 #define AS_ROW_BYTES (8 * AS_PLANE)    // 8 KiB per context
@@ -50,16 +48,10 @@
 #define AS_TOT_BYTES (16 * AS_TOT_ROW)
 #define AS_LUT_BASE (AS_TOT_BASE + AS_TOT_BYTES)
 #define AS_LUT_BYTES 512
-#ifndef AS_TILE
 #define AS_TILE 4                      // symbols per lane and barrier: 2 or 4 (a 32-bit word of symbols is 4 / AS_TILE tiles)
-#endif
 #define AS_RPW (4 / AS_TILE)            // rounds per word of symbols
-#ifndef AS_NBUF
 #define AS_NBUF 1                      // 2: double-buffered FIFOs, one barrier per round; 1: one buffer, consumers take their
-#endif                                 // tile into registers first and a second barrier per round releases the buffer
-#ifndef AS_ABLATE
-#define AS_ABLATE 0  // timing experiments only (outputs invalid), bit mask: 1 no model updates, 2 no coder work, 4 no writer work, 8 no model work at all
-#endif
+                                       // tile into registers first and a second barrier per round releases the buffer
 // FIFO 1 (model -> coder), two buffers of AS_TILE symbols: 1/T as binary64 [buf][j][lane], c | d << 16 [buf][j][lane]
 #define AS_F1X_BASE (AS_LUT_BASE + AS_LUT_BYTES)
 #define AS_F1X_SLOT (AS_LANES * 8)
@@ -140,10 +132,6 @@ __global__ void __launch_bounds__(AS_THREADS)
         const u32 lane4 = lane * 4;
         u32 *tot32 = reinterpret_cast<u32 *>(lds + AS_TOT_BASE) + (lane >> 1);
         for (u32 w = 0; w < n_words; ++w) {
-            if (AS_ABLATE & 8) {
-                for (u32 h = 0; h < AS_RPW * (3 - AS_NBUF); ++h) __syncthreads();
-                continue;
-            }
             const u32 word = nextw;
             nextw = src[min(w + 1, last_word)];  // one word ahead, never conditional
             u32 s[4];
@@ -172,7 +160,7 @@ __global__ void __launch_bounds__(AS_THREADS)
                     w1[j] = *reinterpret_cast<const u32_lds *>(lds + wa + AS_PLANE);
                     T[j] = *reinterpret_cast<const u16_lds *>(lds + AS_TOT_BASE + ctx * AS_TOT_ROW + lane * 2);
                     // update_model: X[j] += 1 for j > s, total += 1 -- no register round trip
-                    if (!(AS_ABLATE & 1)) {
+                    {
                         u32 *row = reinterpret_cast<u32 *>(lds + rowaddr);
                         const u32 add[8] = {la[q].x, la[q].y, la[q].z, la[q].w, lb[q].x, lb[q].y, lb[q].z, lb[q].w};
 #pragma unroll
@@ -224,7 +212,7 @@ __global__ void __launch_bounds__(AS_THREADS)
 #pragma unroll
             for (u32 j = 0; j < AS_TILE; ++j) {
                 const u32 i = (r - 1) * AS_TILE + j;
-                if (r > 0 && i < n && !(AS_ABLATE & 2)) {
+                if (r > 0 && i < n) {
                     const double x = (AS_NBUF == 1) ? xt[j] : *reinterpret_cast<const double *>(lds + AS_F1X_BASE + (buf1 * AS_TILE + j) * AS_F1X_SLOT + lane * 8);
                     const u32 cd = (AS_NBUF == 1) ? cdt[j] : *reinterpret_cast<const u32_lds *>(lds + AS_F1C_BASE + (buf1 * AS_TILE + j) * AS_F1C_SLOT + lane * 4);
                     const double rd = (double)(hm - low) + 1.0;
@@ -331,7 +319,7 @@ __global__ void __launch_bounds__(AS_THREADS)
 #pragma unroll
         for (u32 j = 0; j < AS_TILE; ++j) {
             const u32 i = (r - 2) * AS_TILE + j;
-            if (r > 1 && i < n && !(AS_ABLATE & 4)) {
+            if (r > 1 && i < n) {
                 const uint2 e = (AS_NBUF == 1) ? et[j] : *reinterpret_cast<const uint2 *>(lds + AS_F2_BASE + (buf2 * AS_TILE + j) * AS_F2_SLOT + lane * 8);
                 const u32 k = e.y & 0xFFu, pend = e.y >> 8, top = e.x;
                 // the k E1/E2 steps emit b0, then `pend` copies of !b0, then the other k - 1 bits of top

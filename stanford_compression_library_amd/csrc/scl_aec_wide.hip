@@ -37,14 +37,7 @@ struct AecWideDev {
 // Cells are u16 here (the any-parameter kernels keep u32 cells in the same scratch: these kernels own their zero-filled
 // scratch for one launch and use the first half of it): every count and block total stays below 2^15 (aec_wide_ok), and a
 // group of 16 cells is 32 bytes -- the kernels are bound by the number of bytes their scattered row accesses move.
-#ifndef AW_CELL16
-#define AW_CELL16 1
-#endif
-#if AW_CELL16
 typedef u16 aw_cell;
-#else
-typedef u32 aw_cell;
-#endif
 struct AwRow {  // 16 consecutive cells
     u32 v[16];
 };
@@ -52,7 +45,6 @@ struct AwRow {  // 16 consecutive cells
 __device__ __forceinline__ AwRow aw_load16(const aw_cell *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     AwRow r;
-#if AW_CELL16
     const uint4 a = q[0], b = q[1];
     const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -60,11 +52,6 @@ __device__ __forceinline__ AwRow aw_load16(const aw_cell *p) {
         r.v[2 * j] = w[j] & 0xFFFFu;
         r.v[2 * j + 1] = w[j] >> 16;
     }
-#else
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-    r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w, r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
-    r.v[8] = c.x, r.v[9] = c.y, r.v[10] = c.z, r.v[11] = c.w, r.v[12] = d.x, r.v[13] = d.y, r.v[14] = d.z, r.v[15] = d.w;
-#endif
     return r;
 }
 __device__ __forceinline__ u32 aw_next_ctx(const AecWideDev &P, u32 ctx, u32 s) {  // past_k[1:] + [s], :146-151

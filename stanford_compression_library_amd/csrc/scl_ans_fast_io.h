@@ -13,13 +13,6 @@
 // The ring of a workgroup must start at LDS offset 0 (addresses wrap with a single AND).
 #pragma once
 #include "scl_common.h"
-#ifndef RF_ABLATE
-#define RF_ABLATE 0
-#endif
-#ifndef RD_ABLATE
-#define RD_ABLATE 0
-#endif
-
 
 // Instruction selection follows profiles/r01_ubench_valu_issue_cost.txt: on gfx950 only
 // v_add/v_sub/v_lshrrev/v_ashrrev/v_and/v_or/v_xor/v_mov (VGPR or literal operands) issue at 32 lanes/clk;
@@ -28,9 +21,6 @@
 // so they need no extraction (k1 rides in the byte v_mad_u32_u24 ignores).
 // Measured on the 1 GiB batch: the branch-free form of put() below is slower at 4 waves per SIMD (encode 0.706 vs
 // 0.675 ms) and only wins when a lone wave per SIMD is latency bound (65 536 chunks: 0.240 vs 0.257 ms): off.
-#ifndef SCL_BRANCHFREE_PUT
-#define SCL_BRANCHFREE_PUT 0
-#endif
 template <int THREADS, bool HOLD_HALF_LINE = true>
 struct AnsBackWriter {
     static constexpr u32 RING_BYTES = 32u * THREADS * 4u;  // placed at LDS offset 0 of the workgroup
@@ -66,16 +56,6 @@ struct AnsBackWriter {
     __device__ __forceinline__ void put(char *lds, u32 v, u32 w) {
         const u32 lo2 = (v << nacc) | lo;
         const u32 nacc2 = nacc + w;
-#if SCL_BRANCHFREE_PUT
-        // branch-free: the current word is always written to its ring slot (an incomplete word is simply written
-        // again later); whether the slot advances is arithmetic on the carry out of the 5-bit bit counter
-        *ring_at(lds, ra) = __builtin_bswap32(lo2);
-        const u32 m = 0u - (nacc2 >> 5);                 // all ones iff the word completed (nacc2 < 64)
-        ra = (ra - (m & (THREADS * 4))) & (RING_BYTES - 1);
-        const u32 hi = v >> ((32 - nacc) & 31);          // only used when m != 0, which implies nacc >= 1
-        lo = (hi & m) | (lo2 & ~m);
-        nacc = nacc2 & 31;
-#else
         if (nacc2 >= 32) {  // a word completes only if bits were pending, so 32 - nacc is a valid shift
             *ring_at(lds, ra) = __builtin_bswap32(lo2);
             ra = (ra - THREADS * 4) & (RING_BYTES - 1);
@@ -85,7 +65,6 @@ struct AnsBackWriter {
             lo = lo2;
             nacc = nacc2;
         }
-#endif
     }
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
         if (w > 16) {
@@ -160,18 +139,6 @@ struct AnsBackWriter {
     }
 };
 
-// timing experiments (off in the product): non-temporal hints on whole-line accesses
-typedef u32 scl_u32x4_v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 scl_load16_nt(const uint4 *p) {
-    const scl_u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const scl_u32x4_v *>(p));
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void scl_store16_nt(uint4 *p, const uint4 v) {
-    const scl_u32x4_v t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<scl_u32x4_v *>(p));
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
 // Round-2 back writer: 64-bit bit window -> per-lane LDS ring of 64 words -> whole 128-byte lines stored by quads.
 //
@@ -208,10 +175,7 @@ __device__ __forceinline__ u32 scl_quad_bcast(u32 v) {  // value of lane R of th
 template <int THREADS>
 struct AnsBackWriterL {
     static constexpr u32 FLUSH_MASK = 3;   // the encoder's flush points: every (FLUSH_MASK + 1) x 16 symbols
-#ifndef RF_FLUSH_PHASE_L
-#define RF_FLUSH_PHASE_L 1
-#endif
-    static constexpr u32 FLUSH_PHASE = RF_FLUSH_PHASE_L;  // ... after block 1 (mod 4) of a line
+    static constexpr u32 FLUSH_PHASE = 1;  // ... after block 1 (mod 4) of a line
     static constexpr u32 WG_PER_CU = 2;    // 64 KiB of rings + the 4 KiB table per 256 lanes
     static constexpr u32 LANE_BYTES = 256;                   // one 256-byte ring per lane, 256-byte aligned
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup
@@ -260,7 +224,6 @@ struct AnsBackWriterL {
     // wait too long for its own LDS operations, never too short.
     template <u32 RING_OFF>
     __device__ __forceinline__ void check(char *lds, u32 bits) {
-#ifndef RF_NO_ASM_CHECK
         u32 w, t;
         u64 sv;
         asm volatile(
@@ -278,14 +241,6 @@ struct AnsBackWriterL {
               [off] "i"(RING_OFF)
             : "vcc", "memory");
         (void)lds;
-#else
-        if (__builtin_usub_overflow(room, bits, &room)) {
-            const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
-            *reinterpret_cast<u32 *>(lds + wa) = __builtin_bswap32(word);
-            wa = ((wa - 4u) & 255u) | base;  // one v_add + one v_and_or: the address register is the only state
-            room += 32;
-        }
-#endif
     }
     template <u32 RING_OFF>
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
@@ -308,81 +263,20 @@ struct AnsBackWriterL {
             const char *r = lds + qbase + R * LANE_BYTES;
             const uint4 q0 = *reinterpret_cast<const uint4 *>(r + (l0 & 255u));
             const uint4 q1 = *reinterpret_cast<const uint4 *>(r + ((l0 + 64u) & 255u));
-#if RF_ABLATE & 4  // timing experiment 4: every line is stored over the slot's last line (same instructions, writes merge in L2)
-            u8 *p = wg_out + (scl_quad_bcast<R>(goff0) - 128u + j16);
-            (void)go_s;
-#else
             u8 *p = wg_out + (go_s - 128u + j16);
-#endif
-#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
-#ifdef RF_NT_STORE
-            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
-            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
-#else
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
-#endif
-#else
-            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
-#endif
         }
     }
-    // the two halves of quad_round (round 5 experiment, RF_FLUSH_SPLIT, off): the ring reads of ALL four rounds issued
-    // before the first store waits for any of them -- one LDS round trip per flush point instead of four in a row
-    template <int R>
-    __device__ __forceinline__ void quad_read(const char *lds, u32 f, u32 qbase, u32 j16, uint4 &q0, uint4 &q1) const {
-        if (scl_quad_bcast<R>(f)) {
-            const u32 l0 = scl_quad_bcast<R>(th4) + (132u + j16);
-            const char *r = lds + qbase + R * LANE_BYTES;
-            q0 = *reinterpret_cast<const uint4 *>(r + (l0 & 255u));
-            q1 = *reinterpret_cast<const uint4 *>(r + ((l0 + 64u) & 255u));
-        }
-    }
-    template <int R>
-    __device__ __forceinline__ void quad_store(u8 *wg_out, u32 f, u32 j16, const uint4 &q0, const uint4 &q1) const {
-        if (scl_quad_bcast<R>(f)) {
-#if RF_ABLATE & 4
-            u8 *p = wg_out + (scl_quad_bcast<R>(goff0) - 128u + j16);
-#else
-            u8 *p = wg_out + (scl_quad_bcast<R>(goff) - 128u + j16);
-#endif
-#if !(RF_ABLATE & 2)
-#ifdef RF_NT_STORE
-            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
-            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
-#else
-            *reinterpret_cast<uint4 *>(p) = q0;
-            *reinterpret_cast<uint4 *>(p + 64) = q1;
-#endif
-#else
-            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
-#endif
-        }
-    }
-#ifndef RF_FLUSH_SPLIT
-#define RF_FLUSH_SPLIT 0  // measured neutral (0.5593 vs 0.5597 ms over nine alternations of 100 launches) at ten registers more
-#endif
     // WAVE-UNIFORM call (all 64 lanes), at least every 64 symbols: <= 26 new words on top of <= 31 pending
     __device__ __forceinline__ void flush_quad(char *lds, u8 *wg_out, u32 tid) {
         const u32 f = pend4() >= 128u ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(f != 0)) {
             const u32 qbase = (tid & ~3u) * LANE_BYTES, j16 = 16u * (tid & 3u);
-#if RF_FLUSH_SPLIT
-            uint4 a0, a1, b0, b1, c0, c1, d0, d1;
-            quad_read<0>(lds, f, qbase, j16, a0, a1);
-            quad_read<1>(lds, f, qbase, j16, b0, b1);
-            quad_read<2>(lds, f, qbase, j16, c0, c1);
-            quad_read<3>(lds, f, qbase, j16, d0, d1);
-            quad_store<0>(wg_out, f, j16, a0, a1);
-            quad_store<1>(wg_out, f, j16, b0, b1);
-            quad_store<2>(wg_out, f, j16, c0, c1);
-            quad_store<3>(wg_out, f, j16, d0, d1);
-#else
             quad_round<0>(lds, wg_out, f, qbase, j16);
             quad_round<1>(lds, wg_out, f, qbase, j16);
             quad_round<2>(lds, wg_out, f, qbase, j16);
             quad_round<3>(lds, wg_out, f, qbase, j16);
-#endif
             if (f) {
                 goff -= 128u;
                 th4 ^= 128u;
@@ -470,7 +364,6 @@ struct AnsBackWriterS {
     __device__ __forceinline__ void fold_lo(u32 hi_before, u32 bits) { lo = __builtin_amdgcn_alignbit(hi_before, lo, bits); }
     template <u32 RING_OFF>
     __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check, by hand for the same reason
-#ifndef RF_NO_ASM_CHECK
         u32 w, t;
         u64 sv;
         asm volatile(
@@ -488,16 +381,6 @@ struct AnsBackWriterS {
             : [bits] "v"(bits), [hi] "v"(hi), [lo] "v"(lo), [sel] "s"(0x00010203u), [base] "v"(base), [off] "i"(RING_OFF)
             : "vcc", "memory");
         (void)lds;
-#else
-        if (__builtin_usub_overflow(room, bits, &room)) {
-            const u32 word = __builtin_amdgcn_alignbit(hi, lo, room);
-            *reinterpret_cast<u32 *>(lds + (base + wo)) = __builtin_bswap32(word);
-            // (wo - 4) mod 192: only wo == 0 wraps, and wo - 4 is then a huge unsigned value -- one subtraction and one
-            // unsigned minimum against the constant 188
-            wo = min(wo - 4u, LANE_BYTES - 4u);
-            room += 32;
-        }
-#endif
     }
     template <u32 RING_OFF>
     __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
@@ -518,17 +401,8 @@ struct AnsBackWriterS {
             const uint4 q0 = *reinterpret_cast<const uint4 *>(r + (scl_quad_bcast<R>(rlo) + qj));
             const uint4 q1 = *reinterpret_cast<const uint4 *>(r + (scl_quad_bcast<R>(rhi) + qj));
             u8 *p = wg_out + (scl_quad_bcast<R>(goff) - 128u + j16);
-#if !(RF_ABLATE & 2)  // timing experiment 2: no global stores
-#ifdef RF_NT_STORE
-            scl_store16_nt(reinterpret_cast<uint4 *>(p), q0);
-            scl_store16_nt(reinterpret_cast<uint4 *>(p + 64), q1);
-#else
             *reinterpret_cast<uint4 *>(p) = q0;
             *reinterpret_cast<uint4 *>(p + 64) = q1;
-#endif
-#else
-            asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(p));
-#endif
         }
     }
     __device__ __forceinline__ void line_done() {
@@ -646,9 +520,6 @@ struct CoopLineStore {
     // a[b] = bytes [16 b, 16 b + 16) of this lane's line, which starts at byte `pos` of its row
     __device__ __forceinline__ void store(uint4 *a, u32 pos) const {
         scl_transpose8(a);
-#if RD_ABLATE & 4  // timing experiment: every line is stored over the row's first line (same instruction stream, the writes merge in L2)
-        pos = 0;
-#endif
 #pragma unroll
         // non-temporal: a decoded line is written once, whole, and never read here.  (With per-lane 16-byte pieces the
         // same hint was a disaster -- they then reach memory unmerged; with whole lines it leaves decode unchanged and
@@ -656,32 +527,16 @@ struct CoopLineStore {
         for (int j = 0; j < 8; ++j) {
             typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
             const u32x4_nt t = {a[j].x, a[j].y, a[j].z, a[j].w};
-#if RD_ABLATE & 1  // timing experiment: no global stores
-            asm volatile("" : : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
-#elif defined(RD_PLAIN_STORE)  // timing experiment: ordinary stores (acknowledged by L2, written back later)
-            *reinterpret_cast<u32x4_nt *>(base + (u64)(8 * j) * stride + pos) = t;
-#else
             __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(base + (u64)(8 * j) * stride + pos));
-#endif
         }
     }
 };
-
 
 struct Line128 {
     uint4 v[8];
     __device__ __forceinline__ void load(const uint4 *p) {
 #pragma unroll
-#ifdef RF_NT_LOAD
-        for (int i = 0; i < 8; ++i) v[i] = scl_load16_nt(p + i);
-#else
         for (int i = 0; i < 8; ++i) v[i] = p[i];
-#endif
-    }
-    // cooperative form: v[i] = this lane's piece of the line of lane (lane & 7) + 8 i; scl_transpose8 completes it
-    __device__ __forceinline__ void load_coop(const uint4 *p, u64 step16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = p[i * step16];
     }
 };
 
@@ -697,9 +552,6 @@ struct AnsBitReader {
     const uint4 *base;
     u64 n_blocks16;  // readable 16-byte blocks
     u64 next_line;   // index of the next 128-byte line to prefetch
-#if RD_ABLATE & 2
-    u64 abl_j0;
-#endif
     uint4 pf[8];     // prefetched line: its two 64-byte halves enter the ring one at a time
     u32 stage;       // 0: the lower half of pf is next, 1: the upper half
     u32 ra;          // LDS byte address of the next ring word to read (thread column, wraps inside the ring)
@@ -718,11 +570,7 @@ struct AnsBitReader {
         if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
-#ifdef RD_NT_LOAD
-            for (int i = 0; i < 8; ++i) pf[i] = scl_load16_nt(p + i);
-#else
             for (int i = 0; i < 8; ++i) pf[i] = p[i];
-#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -777,11 +625,7 @@ struct AnsBitReader {
             } else {
                 push_half(lds, pf[4], pf[5], pf[6], pf[7]);
                 stage = 0;
-#if RD_ABLATE & 2  // timing experiment: after the header every lane keeps re-reading two lines (cache hits; decodes garbage)
-                load_line(abl_j0 + (next_line++ & 1));
-#else
                 load_line(next_line++);
-#endif
             }
         }
     }
@@ -803,9 +647,6 @@ struct AnsBitReader {
         push_half(lds, pf[4], pf[5], pf[6], pf[7]);
         load_line(j0 + 1);
         next_line = j0 + 2;
-#if RD_ABLATE & 2
-        abl_j0 = j0;
-#endif
         stage = 0;
         const u32 w0 = (u32)(bit_off >> 5) & 31u;
         ra = tid * 4 + w0 * THREADS * 4;
@@ -841,7 +682,6 @@ struct AnsBitReader {
         return v;
     }
 };
-
 
 // Round-4 reader: no bit window in registers.  AnsBitReader keeps two ring words (A, B) in registers and advances
 // them under a branch that the whole wave runs for every pair of symbols (some lane always crosses a word: 5 VALU + 2 SALU
@@ -883,11 +723,7 @@ struct AnsBitReaderW {
         if (!ZERO_PAST_END && j * 8 + 8 <= n_blocks16) {
             const uint4 *p = base + j * 8;
 #pragma unroll
-#ifdef RD_NT_LOAD
-            for (int i = 0; i < 8; ++i) pf[i] = scl_load16_nt(p + i);
-#else
             for (int i = 0; i < 8; ++i) pf[i] = p[i];
-#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -991,7 +827,6 @@ struct AnsBitReaderW {
     }
 };
 
-
 // Forward twin of AnsBackWriter for streams that grow front to back (arithmetic coder): completed big-endian
 // words go to the per-lane LDS ring ([word][thread], at LDS offset 0) and leave for memory as whole 128-byte lines
 // (the first 64-byte half waits in registers), so that a lane only ever stores whole, aligned lines.
@@ -1064,9 +899,6 @@ struct AnsFwdWriter {
             const uint4 q2 = make_uint4(w[8], w[9], w[10], w[11]), q3 = make_uint4(w[12], w[13], w[14], w[15]);
             if (have_held) {  // second half of the line whose first half is held
                 uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
-#ifdef FW_ABLATE_NOSTORE  // timing experiment
-                asm volatile("" : : "v"(held[0].x), "v"(held[1].x), "v"(held[2].x), "v"(held[3].x), "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
-#else
                 p[0] = held[0];
                 p[1] = held[1];
                 p[2] = held[2];
@@ -1075,7 +907,6 @@ struct AnsFwdWriter {
                 p[5] = q1;
                 p[6] = q2;
                 p[7] = q3;
-#endif
                 have_held = 0;
             } else {
                 held[0] = q0;

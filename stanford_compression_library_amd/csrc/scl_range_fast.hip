@@ -69,10 +69,6 @@ struct RgOut {
     }
     // append nbits / 8 (0..4) bytes: `bytes` is their big-endian number (the first byte in stream order the most significant)
     __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nbits) {
-#if defined(RG_ABLATE) && (RG_ABLATE & 2)
-        asm volatile("" : : "v"(bytes), "v"(nbits));
-        return;
-#endif
         acc = (acc << nbits) | bytes;
         cnt += nbits;
         if (cnt >= 32) {
@@ -87,10 +83,7 @@ struct RgOut {
     // SIMD) and spill 52-68 bytes with the transpose
     template <bool COOP = false>
     __device__ __forceinline__ void maybe_flush(char *lds) {
-#ifndef RG_COOP_STORE
-#define RG_COOP_STORE 1
-#endif
-        if (RG_COOP_STORE && COOP && coop) {  // (wave-uniform; every lane of the wave makes this call)
+        if (COOP && coop) {  // (wave-uniform; every lane of the wave makes this call)
             const bool full = pend >= 16 && have_held;
             if (__builtin_amdgcn_ballot_w64(full && nfl == (u32)__builtin_amdgcn_readfirstlane((int)nfl)) == ~0ull) {
                 const char *r = lds + fa;
@@ -105,11 +98,7 @@ struct RgOut {
                     u8 *p = coop_base + 4 * (u64)(nfl - 16);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-#ifndef RG_ABLATE_NOSTORE
                         *reinterpret_cast<uint4 *>(p + (u64)(8 * j) * stride) = a[j];
-#else
-                        asm volatile("" : : "v"(a[j].x), "v"(p));
-#endif
                     }
                 } else {
                     overflow = 1;
@@ -131,7 +120,6 @@ struct RgOut {
             if (have_held) {  // second half of a line: store the whole 128 bytes at once
                 if (4 * (u64)nfl + 64 <= cap) {
                     uint4 *p = reinterpret_cast<uint4 *>(slot + 4 * (u64)(nfl - 16));
-#ifndef RG_ABLATE_NOSTORE
                     p[0] = held[0];
                     p[1] = held[1];
                     p[2] = held[2];
@@ -140,9 +128,6 @@ struct RgOut {
                     p[5] = q1;
                     p[6] = q2;
                     p[7] = q3;
-#else
-                    asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(p));
-#endif
                 } else {
                     overflow = 1;
                 }
@@ -276,10 +261,7 @@ __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uin
     nb = sh;  // in BITS
     low = (u32)l64;
     range = range_s;
-#ifndef RG_ABLATE
-#define RG_ABLATE 0  // timing experiments (wrong output): 1 = no rare-path branch, 2 = nothing leaves the byte accumulator
-#endif
-    if (!(RG_ABLATE & 1) && __builtin_expect(range_s < RG_BOTTOM, 0)) {
+    if (__builtin_expect(range_s < RG_BOTTOM, 0)) {
         low = low0;
         range = range0;
         bytes = 0;
@@ -344,10 +326,6 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
         for (int j = 0; j < 4; j += 2) {
             if (!RG_UNI(MODE)) bad = max(bad, max(a[j], a[j + 1]));
             u32 b0, n0, b1, n1;  // n0, n1: bits
-#ifndef RG_PAIR_REPLAY
-#define RG_PAIR_REPLAY 1  // 0: one rare-path branch per symbol and a third for pairs of more than four bytes (rounds 2-4)
-#endif
-#if RG_PAIR_REPLAY
             // Both symbols on the common path, unconditionally; ONE test and one branch per pair for everything else -- a
             // carry-less reset in either symbol, more than a word of bytes from the two together -- whose lanes replay the
             // pair from the state of before it, symbol by symbol, with the exact routine.  (Was: a branch per symbol, a
@@ -368,17 +346,6 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
             } else {
                 o.put_bytes(lds, (b0 << n1) | b1, nn);
             }
-#else
-            u32 z0 = 0, zn = 0;
-            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j]), md, b0, n0, z0, zn, o, lds);
-            rg_encode_symbol<MODE>(low, range, rg_entry<MODE>(tab, a[j + 1]), md, b1, n1, b0, n0, o, lds);
-            if (n0 + n1 <= 32) {  // each <= 24
-                o.put_bytes(lds, (b0 << n1) | b1, n0 + n1);
-            } else {
-                o.put_bytes(lds, b0, n0);
-                o.put_bytes(lds, b1, n1);
-            }
-#endif
         }
     }
     o.template maybe_flush<RG_UNI(MODE)>(lds);
@@ -392,10 +359,7 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
                                                                           u64 out_stride, u64 *__restrict__ out_bit_off,
                                                                           u32 *__restrict__ out_nbits,
                                                                           u32 *__restrict__ status) {
-    #ifndef RGE_LDS_PAD
-#define RGE_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
-#endif
-    __shared__ __attribute__((aligned(16))) char s_lds[RGE_RING_BYTES + 256 * 8 + RGE_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) char s_lds[RGE_RING_BYTES + 256 * 8];
     char *lds = s_lds;
     const char *tab = s_lds + RGE_RING_BYTES;
     reinterpret_cast<uint2 *>(s_lds + RGE_RING_BYTES)[threadIdx.x & 255] = P.d_enc_tab[threadIdx.x & 255];
@@ -590,17 +554,10 @@ __device__ __forceinline__ u32 rg_div32(u32 d, u32 r) {
     u32 q;  // q or q - 1
     asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(qf));
     const u32 rem = d - __umul24(q, r);   // q < 2^17, r < 2^24; rem in [0, 2r)
-#ifndef RGD_SUBB
-#define RGD_SUBB 1  // 0: v_cmp_ge + v_addc (2.8 + 1.9 ns) instead of v_sub_co + v_subb (1.9 + 1.9)
-#endif
-#if RGD_SUBB
     u32 t, qn;  // q + 1 - [rem < r]: the borrow of rem - r IS the test
     asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_subb_co_u32 %1, vcc, %4, -1, vcc"
         : "=&v"(t), "=v"(qn) : "v"(rem), "v"(r), "v"(q) : "vcc");
     return qn;
-#else
-    return q + (rem >= r ? 1u : 0u);
-#endif
 }
 
 // one symbol: search (:225-238), shrink_range, normalize (:240-267); returns the symbol
@@ -654,20 +611,12 @@ __device__ __forceinline__ u32 rg_decode_fast(u32 &low, u32 &range, u32 &state, 
     const u64 t = ((((u64)state) << 32) | lk) << sh;
     state = (u32)(t >> 32);
     lk = (u32)t;
-#ifndef RGD_PACKED_SHIFT
-#define RGD_PACKED_SHIFT 1  // 0: low and range shifted by two instructions
-#endif
-#if RGD_PACKED_SHIFT
     // low and low + range agree on their top sh bits, so range0 < 2^(32 - sh): shifting the pair low0 : range0 left by sh
     // moves nothing of range0 into low0's word -- one 64-bit shift for both (the bytes leaving the top of low0 are not
     // needed here: the decoder reads them from the stream)
     const u64 lr = ((((u64)low0) << 32) | range0) << sh;
     low = (u32)(lr >> 32);
     range = (u32)lr;
-#else
-    low = low0 << sh;
-    range = range0 << sh;
-#endif
     nb = sh;
     left = range;
     return s;
@@ -787,22 +736,12 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
         if (status) status[c] = SCL_ST_TRUNCATED;
         return;
     }
-#ifndef RGD_PAIR
-#define RGD_PAIR 1  // 0: the round-1..4 reader (two ring words in registers, advanced under a branch per symbol)
-#endif
-#if RGD_PAIR
     // the rANS decoder's windowless reader (scl_ans_fast_io.h): the 32 bits at the position come straight out of the ring,
     // once per PAIR of symbols; nothing is advanced under a branch
     AnsBitReaderW<RGD_THREADS> r;
     r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, 32);
     u32 state = r.get(lds, 32);  // the first four bytes of the body (:289-291)
-#else
-    RgIn r;
-    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
-    u32 n = r.get32(lds);
-    u32 state = r.get32(lds);  // the first four bytes of the body (:289-291)
-#endif
     out_lens[c] = n;
     if (n > out_cap) {
         st |= SCL_ST_CAPACITY;
@@ -831,7 +770,6 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 u32 o = 0;
-#if RGD_PAIR
                 // Both symbols of a pair on the common path out of ONE 32-bit look-ahead, unconditionally; one test and one
                 // branch per pair for everything else (a carry-less reset in either symbol, more than 32 bits for the two):
                 // those lanes replay the pair from the state of before it with the exact routine.
@@ -843,11 +781,7 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                     u32 s0 = rg_decode_fast<MODE, LUT, DIV32>(low, range, state, lk, n0, l0, tab, md, slot_max);
                     u32 s1 = rg_decode_fast<MODE, LUT, DIV32>(low, range, state, lk, n1, l1, tab, md, slot_max);
                     const u32 nn = n0 + n1;
-#ifdef RGD_ABLATE_NOSLOW  // timing experiment (wrong output on rare lanes): no replay code at all
-                    if (0) {
-#else
                     if (__builtin_expect((min(l0, l1) < RG_BOTTOM) | (nn > 32), 0)) {
-#endif
                         low = low_s;
                         range = range_s;
                         state = state_s;
@@ -859,27 +793,14 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
                     o |= (s0 << (8 * j)) | (s1 << (8 * j + 8));
                 }
                 if (d & 1) r.maybe_refill(lds);  // every eight symbols: <= 8 words even if each took the four-byte path
-#else
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32 s = rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);
-                    o |= s << (8 * j);
-                }
-                r.maybe_refill(lds);
-#endif
                 asm volatile("" : "+v"(o) : : "memory");
                 ow[d] = o;
             }
             a[b] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
         uint4 *p = reinterpret_cast<uint4 *>(dst + i);
-#ifdef RGD_ABLATE_NOSTORE  // timing experiment
-#pragma unroll
-        for (int b = 0; b < 8; ++b) asm volatile("" : : "v"(a[b].x), "v"(a[b].y), "v"(a[b].z), "v"(a[b].w), "v"(p));
-#else
 #pragma unroll
         for (int b = 0; b < 8; ++b) p[b] = a[b];
-#endif
     }
     for (; i < n; ++i) {  // ragged tail
         dst[i] = (u8)rg_decode_symbol<MODE, LUT, DIV32>(low, range, state, r, lds, tab, md, slot_max);

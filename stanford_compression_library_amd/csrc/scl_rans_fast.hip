@@ -34,27 +34,6 @@
 #include "scl_rans_internal.h"
 
 #define RF_THREADS 256
-#ifndef RD_WINDOWLESS
-#define RD_WINDOWLESS 1  // 0: the round-1..3 reader (two ring words in registers, advanced under a branch per pair)
-#endif
-#ifndef RF_UNROLL2
-#define RF_UNROLL2 0  // 1: the encoder's line loop handles two lines per iteration (no copy of the prefetched line)
-#endif
-#ifndef RF_WAITMERGE
-#define RF_WAITMERGE 1  // 0: one s_waitcnt per symbol for its table entry (round 3)
-#endif
-#ifndef RD_PERM_PAIRS
-#define RD_PERM_PAIRS 1  // 0: one v_perm per decoded symbol
-#endif
-#ifndef RF_SHIFT64
-#define RF_SHIFT64 1  // 0: x >> k and the window's high word as two instructions (v_lshrrev + v_alignbit, rounds 2-4)
-#endif
-#ifndef RF_PAIR_FOLD
-#define RF_PAIR_FOLD 1  // 0: the window's low word follows every symbol (two v_alignbit per push, rounds 2-4)
-#endif
-#ifndef RF_COOP_STORE
-#define RF_COOP_STORE 1  // 0 (timing experiment): every lane stores its own lines
-#endif
 
 __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
 
@@ -115,15 +94,10 @@ __device__ __forceinline__ u32 rf_encode_entry(u32 &x, const EncEntry e, u32 msh
         pos = q0 >> ((msh_rt >> 16) + 1u);
     }
     const u32 k = e.k_lo + pos;  // a plain add: a byte of another word would cost an SDWA form, 1.75 instead of 1.05 ns
-#if RF_SHIFT64  // x >> k and the window's new high word are the two halves of ONE 64-bit shift of x : hi (v_lshrrev_b64,
                 // 2.5 ns where v_lshrrev + v_alignbit cost 2.8 and two issue slots: 0.5568 -> 0.5468 ms, nine alternations)
     const u64 t = ((((u64)x) << 32) | o.hi) >> k;
     o.hi = (u32)t;
     x = rf_mad24(q0 >> pos, e.mf, (u32)(t >> 32) + e.c);
-#else
-    o.push_hi(x, k);             // (the caller folds the window's low word: once per pair of symbols, RF_PAIR_FOLD)
-    x = rf_mad24(q0 >> pos, e.mf, (x >> k) + e.c);
-#endif
     return k;
 }
 
@@ -142,37 +116,21 @@ __device__ __forceinline__ u32 rf_encode_entry_b(u32 &x, const EncEntry e, u32 m
                                                                // v_lshrrev_b32 reads five bits, the backend drops it)
     const u32 posb = (q0 >> ((msh_rt >> 16) & 0xFFu)) ? (msh_rt >> 24) : 0u;
     const u32 k = (e.k_lo >> 8) + posb;
-#if RF_SHIFT64
     const u64 t = ((((u64)x) << 32) | o.hi) >> k;  // k <= 16
     o.hi = (u32)t;
     x = rf_mad24(q0 >> posb, e.mf, (u32)(t >> 32) + e.c);
-#else
-    o.push_hi(x, k);
-    x = rf_mad24(q0 >> posb, e.mf, (x >> k) + e.c);
-#endif
     return k;
 }
 
 struct Entries4 {
     EncEntry e[4];
     __device__ __forceinline__ void load(u32 w, const char *tab) {
-#ifdef RF_ABLATE_NOCONFLICT  // timing experiment: every lane reads the entries of (lane-independent) symbols -> broadcast, no bank conflict
-        w = (u32)__builtin_amdgcn_readfirstlane((int)w);
-#endif
         // byte 0 like the other three: one SDWA shift (the compiler turns (w & 0xFF) << 4 into a shift and a mask)
         u32 a0;
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
             : "=v"(a0)
             : "v"(4u), "v"(w));
-#ifdef RF_ABLATE_B64  // timing experiment: 8-byte table reads (c = 0: garbage output, same flow)
-#define RF_LOAD_ENTRY(dst, addr)                                                \
-    do {                                                                        \
-        const uint2 t2 = *reinterpret_cast<const uint2 *>(tab + (addr));        \
-        dst.rcp = t2.x, dst.mf = t2.y & 0xFFFFu, dst.c = 0, dst.k_lo = t2.y >> 24;                 \
-    } while (0)
-#else
 #define RF_LOAD_ENTRY(dst, addr) dst = *reinterpret_cast<const EncEntry *>(tab + (addr))
-#endif
         RF_LOAD_ENTRY(e[0], a0);
         RF_LOAD_ENTRY(e[1], (w >> 4) & 0xFF0u);
         RF_LOAD_ENTRY(e[2], (w >> 12) & 0xFF0u);
@@ -199,13 +157,9 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
         const Entries4 cur = pre;
         pre.load(wv[d + 1], tab);
         asm volatile("" ::: "memory");  // keep the reads here: the compiler would sink them to their first use
-#if RF_WAITMERGE == 1
         // the four entries of this word were issued back to back a whole word ago: touching the LAST of them first makes the
         // compiler wait once (lgkmcnt(4): only the reads just issued may still be in flight) instead of once per symbol
         asm volatile("" : : "v"(cur.e[3].k_lo));
-#elif RF_WAITMERGE == 2  // experiment: two waits per word
-        asm volatile("" : : "v"(cur.e[1].k_lo));
-#endif
         if (CHECK_SYM) {
             const u32 w = wv[d];
             const u32 t = (w & 0x7F7F7F7Fu) + chk_c;
@@ -217,25 +171,22 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
         const u32 h0 = o.hi;
         const u32 k0 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[0], msh_rt, o) : rf_encode_entry_b(x, cur.e[0], msh_rt, o);
         const u32 h1 = o.hi;
-        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h0, k0);
+        if (NB_T != 1) o.fold_lo(h0, k0);
         const u32 k1 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[1], msh_rt, o) : rf_encode_entry_b(x, cur.e[1], msh_rt, o);
-        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h1, k1); else o.fold_lo(h0, k0 + k1);
+        if (NB_T != 1) o.fold_lo(h1, k1); else o.fold_lo(h0, k0 + k1);
         o.template check<RF_RING_OFF>(lds, k0 + k1);
         const u32 h2 = o.hi;
         const u32 k2 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[2], msh_rt, o) : rf_encode_entry_b(x, cur.e[2], msh_rt, o);
         const u32 h3 = o.hi;
-        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h2, k2);
+        if (NB_T != 1) o.fold_lo(h2, k2);
         const u32 k3 = NB_T == 1 ? rf_encode_entry<MSH_T, R_T>(x, cur.e[3], msh_rt, o) : rf_encode_entry_b(x, cur.e[3], msh_rt, o);
-        if (NB_T != 1 || !RF_PAIR_FOLD) o.fold_lo(h3, k3); else o.fold_lo(h2, k2 + k3);
+        if (NB_T != 1) o.fold_lo(h3, k3); else o.fold_lo(h2, k2 + k3);
         o.template check<RF_RING_OFF>(lds, k2 + k3);
     }
 }
 
-#ifndef RF_WAVES_ATTR
-#define RF_WAVES_ATTR
-#endif
 template <typename EncOut, int CHECK_SYM, int MSH_T, int R_T, int NB_T = 1>
-__global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+__global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
                                                                         u64 n_chunks, u8 *__restrict__ out,
@@ -244,10 +195,7 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
                                                                         u32 *__restrict__ status) {
     // one LDS block: the 4 KiB symbol table first (its offsets then fit the 16-bit offset field of the DS instructions;
     // behind the rings, every table address cost an extra VALU instruction), then 64 KiB of word rings
-#ifndef RF_LDS_PAD
-#define RF_LDS_PAD 0  // timing experiment: unused LDS, to lower the number of resident workgroups
-#endif
-    __shared__ __attribute__((aligned(16))) char s_lds[RF_RING_OFF + EncOut::RING_BYTES + RF_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) char s_lds[RF_RING_OFF + EncOut::RING_BYTES];
     char *lds = s_lds + RF_RING_OFF;
     const char *tab = s_lds;
     static_assert(RF_RING_OFF == 256 * sizeof(uint4), "the rings start right behind the symbol table");
@@ -264,8 +212,7 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     EncOut o;
     o.init(threadIdx.x, (threadIdx.x + 1) * (u32)out_stride);
     // whole wave, equally long chunks: every lane reaches every flush point, so the quads can store cooperatively
-    const bool coop_out =
-        RF_COOP_STORE && __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
+    const bool coop_out = __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
 #define RF_FLUSH()                                 \
     do {                                           \
         if (coop_out)                              \
@@ -280,24 +227,10 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     // One 128-byte line per tile.
     const u32 n_lines = n >> 7;
     const uint4 *src16 = reinterpret_cast<const uint4 *>(src);
-#ifndef RF_COOP_LOAD
-#define RF_COOP_LOAD 0
-#endif
-    // RF_COOP_LOAD = 1 (experiment): whole waves of equally long chunks load their 64 lines cooperatively (instruction i
-    // = the lines of the lanes l0 + 8 i, lane (l0, k) the k-th 16-byte piece) and transpose them in registers
-    const u32 lane = threadIdx.x & 63u;
-    const bool coop_in = RF_COOP_LOAD && coop_out && n_lines != 0;
-    const uint4 *cp16 = reinterpret_cast<const uint4 *>(sym + (c - lane + (lane & 7u)) * sym_stride) + (lane >> 3);
-    const u64 step16 = sym_stride >> 1;  // 8 rows further, in 16-byte units
     Line128 cur, nxt;
     Entries4 pre;
     if (n_lines) {
-        if (coop_in) {
-            cur.load_coop(cp16, step16);
-            scl_transpose8(cur.v);
-        } else {
-            cur.load(src16);
-        }
+        cur.load(src16);
         pre.load(cur.v[0].x, tab);
     }
     // one line = eight blocks of 16 symbols, straight-line code: an inner loop holding only stores would make the compiler
@@ -315,42 +248,13 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) RF_WAVES_ATTR r
     }
     // prefetch the next line while this one is encoded; unconditional (the last line is simply loaded again): a load
     // under a lane-dependent condition is merged with the old value, i.e. waited for, at once
-#if RF_ABLATE & 8  // timing experiment 8: no input loads after the first line
-#define RF_LOAD_LINE(L, T)                    \
-    do {                                      \
-        L = cur;                              \
-        asm volatile("" : "+v"(L.v[0].x));    \
-    } while (0)
-#else
-#define RF_LOAD_LINE(L, T)                                                  \
-    do {                                                                    \
-        if (coop_in)                                                        \
-            L.load_coop(cp16 + 8 * min((T), n_lines - 1), step16);          \
-        else                                                                \
-            L.load(src16 + 8 * min((T), n_lines - 1));                      \
-    } while (0)
-#endif
+#define RF_LOAD_LINE(L, T) L.load(src16 + 8 * min((T), n_lines - 1))
     u32 t = 0;
-#if RF_UNROLL2
-    // two lines per iteration, the two register buffers taking turns: no 32-register copy per line
-#pragma nounroll
-    for (; t + 2 <= n_lines; t += 2) {
-        RF_LOAD_LINE(nxt, t + 1);
-        RF_ENCODE_LINE(cur)
-        if (coop_in) scl_transpose8(nxt.v);
-        pre.load(nxt.v[0].x, tab);
-        RF_LOAD_LINE(cur, t + 2);
-        RF_ENCODE_LINE(nxt)
-        if (coop_in) scl_transpose8(cur.v);
-        pre.load(cur.v[0].x, tab);
-    }
-#endif
 #pragma nounroll
     for (; t < n_lines; ++t) {
         RF_LOAD_LINE(nxt, t + 1);
         RF_ENCODE_LINE(cur)
         cur = nxt;
-        if (coop_in) scl_transpose8(cur.v);
         pre.load(cur.v[0].x, tab);
     }
 #undef RF_ENCODE_LINE
@@ -511,7 +415,6 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
             // symbol's three don't-care bits are whatever follows); the top-aligned variants report their shift, 3 more
             // per symbol than they read
             r.advance(lds, ((ML_T >= 0 && CB_T == 3) || NB_T != 1) ? ua + ub - 6u : ua + ub);
-#if RD_PERM_PAIRS
             // the symbol bytes of a pair with ONE v_perm (the earlier symbol is the more significant byte), the two pairs
             // of a word with another: three instead of four per four symbols
             u32 p = __builtin_amdgcn_perm(ea, eb, 0x0c0c0703u);  // 0 : 0 : ea >> 24 : eb >> 24
@@ -519,19 +422,8 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
             // of a 64-symbol iteration to its end, keeps every table word alive until then and spills
             asm volatile("" : "+v"(p) : : "memory");
             pr[h] = p;
-#else
-            u32 o = pr[0];
-            o = __builtin_amdgcn_perm(o, ea, 0x06050403u);  // o = (o << 8) | (ea >> 24)
-            o = __builtin_amdgcn_perm(o, eb, 0x06050403u);
-            asm volatile("" : "+v"(o) : : "memory");
-            pr[0] = pr[1] = o;
-#endif
         }
-#if RD_PERM_PAIRS
         ow[d] = __builtin_amdgcn_perm(pr[0], pr[1], 0x05040100u);
-#else
-        ow[d] = pr[1];
-#endif
     }
     if (REFILL) r.maybe_refill(lds);
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
@@ -548,11 +440,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
                                                                      u32 *__restrict__ status) {
     // slot table first: its offsets (< 32 KiB) then need no base added (a DS offset field reaches 64 KiB); the ring
     // works on addresses relative to its own base, which the DS offset field supplies
-#if RD_WINDOWLESS
     typedef AnsBitReaderW<THREADS> DecIn;
-#else
-    typedef AnsBitReader<THREADS> DecIn;
-#endif
     __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + DecIn::RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;

@@ -185,8 +185,13 @@ def test_bench_two_ranks_on_one_gpu(ranks):
     g = out["gather"]  # configs[4]: encode -> compact -> gather, sequential and as a pipeline of sub-batches
     assert g["gathered_bytes"] > ranks * 4096 * 3000 and g["blocks_1MiB"] == ranks * 4096 // 256
     assert all(g[k] > 0 for k in ("encode_ms", "compact_ms", "gather_ms", "sequential_ms", "overlapped_ms"))
-    assert g["verified"].startswith("per-rank size")  # the root checked what it received against the ranks' checksums
+    assert g["verified"] is True  # the root checked what it received against the ranks' checksums (sentence: full record)
+    assert "rccl_ranks" in g  # None on the shared-GPU gloo path, == ranks over RCCL
     assert list(out)[-1] == "summary" and len(json.dumps(out["summary"])) <= 1024
+    # the multi-GPU line, too, is one the driver can hold and parse
+    assert len(lines[0]) < 6144 and out["full_record"]
+    full = json.loads(open(os.path.join(root, out["full_record"])).read())
+    assert full["gather"]["verified"].startswith("per-rank size") and full["value"] == out["value"]
 
 
 @pytest.mark.gpu
