@@ -69,7 +69,7 @@ def host_cores():
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOAD_FLAGS = ("chunks", "chunk_len", "table", "coder", "aec_K", "aec_model", "num_bits_out", "range_factor", "source",
-                  "sym_pad")
+                  "sym_pad", "layout")
 
 
 def parse_args(argv=None):
@@ -90,6 +90,10 @@ def parse_args(argv=None):
                          "symbols, or AdaptiveIIDFreqModel (all-ones start, 256 symbols) on the same i.i.d. symbols")
     ap.add_argument("--num-bits-out", type=int, default=1, help="rANS NUM_BITS_OUT (reference default 1)")
     ap.add_argument("--range-factor", type=int, default=1 << 16, help="rANS RANGE_FACTOR (reference default 2^16)")
+    ap.add_argument("--layout", choices=["auto", "linear", "striped"], default="auto",
+                    help="slot layout of the rANS / tANS batches: wave-striped slots (ABI 8: four waves per SIMD in the "
+                         "encoder, row-by-row stores) for batches that fill the chip, linear slots otherwise (auto); the "
+                         "other coders have linear slots only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pipeline", action="store_true",
                     help="skip the two-sub-batch pipelined dense encode (roofline_dense.pipelined_ms): it launches the encode "
@@ -318,7 +322,7 @@ def cpu_baseline(w, spec, sym_dev, enc, target_seconds=10.0):
     assert np.array_equal(g_nbits, nbits), "GPU/oracle stream lengths differ"
     checked = 0
     if n * enc.stride < (1 << 31):
-        data = enc.data[:n * enc.stride + 16].cpu().numpy()
+        data = linear_slots(enc, n).cpu().numpy()
         offs = enc.bit_offset[:n].cpu().numpy()
         streams = [e[0] for e in enc_parts]
         for c in range(0, n, max(1, n // 64)):
@@ -367,7 +371,7 @@ def restatement_baseline(w, spec, sym_dev, enc):
     assert r["ok"], "restatement round trip failed"
     checked = 0
     if n * enc.stride < (1 << 31):
-        data = enc.data[:n * enc.stride + 16].cpu().numpy()
+        data = linear_slots(enc, n).cpu().numpy()
         offs, nbits = enc.bit_offset[:r["chunks"]].cpu().numpy(), enc.nbits[:r["chunks"]].cpu().numpy()
         for c, (nb, payload) in enumerate(r["streams"]):
             assert nb == int(nbits[c]), f"chunk {c}: GPU/restatement stream lengths differ"
@@ -387,7 +391,19 @@ def restatement_baseline(w, spec, sym_dev, enc):
     }
 
 
-def rocprof_kernel_names(w, model):
+def linear_slots(enc, n):
+    """the first n logical slots of an encoded batch as one linear byte tensor (+16): what `bit_offset` indexes.  A copy
+    for striped batches (a permutation of 16-byte pieces) -- the CPU baselines compare sampled streams bit for bit"""
+    import torch
+
+    if enc.layout == "linear":
+        return enc.data[: n * enc.stride + 16]
+    n64 = (n + 63) // 64
+    body = enc.data[: n64 * 64 * enc.stride].view(n64, enc.stride // 16, 64, 16).permute(0, 2, 1, 3).reshape(-1)
+    return torch.cat([body[: n * enc.stride], body.new_zeros(16)])
+
+
+def rocprof_kernel_names(w, model, layout="linear"):
     """the names rocprofv3 prints for the two kernels of the timed step, from the library itself (C ABI 6:
     scl_rans_kernel_names / scl_tans_kernel_names report the instantiation the launch code picks for this model and batch
     size), so that the line can be matched mechanically with profiles/*_kernel_trace_summary.txt
@@ -395,16 +411,18 @@ def rocprof_kernel_names(w, model):
     import ctypes as C
 
     if w.coder in ("rans", "tans"):
-        enc, dec = C.create_string_buffer(160), C.create_string_buffer(160)
-        rc = getattr(model._L, f"scl_{w.coder}_kernel_names")(model._h, int(w.chunks), enc, dec, 160)
-        if rc == 0:
-            return enc.value.decode(), dec.value.decode()
+        try:
+            return model.kernel_names(int(w.chunks), layout)
+        except Exception:
+            pass
     return f"{w.coder}_encode", f"{w.coder}_decode"
 
 
-def traffic_key(w, freq):
+def traffic_key(w, freq, layout="linear"):
     """what a PMC pass must have been taken on to be quoted for this run (tools/make_traffic_json.py stores it)"""
     key = {"coder": w.coder, "chunks": w.chunks, "chunk_len": w.chunk_len}
+    if layout != "linear":
+        key["layout"] = layout
     if w.coder == "aec" and w.aec_model == "order1":
         key.update(model="order1", K=w.aec_K)
     else:
@@ -534,12 +552,13 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
     else:
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
     model, coder_params, spec = make_model(w, freq)
-    kernels = rocprof_kernel_names(w, model)
+    layout = model.pick_layout(getattr(w, "layout", "auto"), n_chunks) if w.coder in ("rans", "tans") else "linear"
+    kernels = rocprof_kernel_names(w, model, layout)
     if w.sym_pad:
         padded = torch.zeros((n_chunks, chunk_len + w.sym_pad), dtype=torch.uint8, device=dev)
         padded[:, :chunk_len] = sym
         sym = padded[:, :chunk_len]
-    enc = model.alloc_encoded(n_chunks, chunk_len, dev)
+    enc = model.alloc_encoded(n_chunks, chunk_len, dev, layout=layout)
     dec_out = model.alloc_decoded(n_chunks, chunk_len, dev)
 
     def step(events=None):
@@ -548,7 +567,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
         model.encode_batch(sym, out=enc)
         if events is not None:
             events[1].record()
-        model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec_out)
+        model.decode_encoded(enc, chunk_len, out=dec_out)
         if events is not None:
             events[2].record()
 
@@ -595,11 +614,11 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
     # (the write-back of those lines is paid by whoever runs next: VERDICT r4 weak #9 -- the spread is in the line now)
     wd.enter(f"{w.coder}: decode after decode")
     n_dd = max(3, min(steps, 20))
-    model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec_out)
+    model.decode_encoded(enc, chunk_len, out=dec_out)
     dd = [torch.cuda.Event(enable_timing=True) for _ in range(n_dd + 1)]
     dd[0].record()
     for i in range(n_dd):
-        model.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_len, out=dec_out)
+        model.decode_encoded(enc, chunk_len, out=dec_out)
         dd[i + 1].record()
     torch.cuda.synchronize()
     dec_after_dec_ms = float(np.mean([dd[i].elapsed_time(dd[i + 1]) for i in range(n_dd)]))
@@ -637,7 +656,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
         # device).  Timed as a whole -- encode included -- and checked byte for byte against the sequential result.
         if not model._needs_scratch and n_chunks >= 4096 and not getattr(w, "no_dense_pipeline", False):
             wd.enter(f"{w.coder}: pipelined dense encode")
-            pipe = _m.DensePipeline(model, n_chunks, chunk_len, dev, n_sub=2)
+            pipe = _m.DensePipeline(model, n_chunks, chunk_len, dev, n_sub=2, layout=layout)
             p_dense, p_offs = pipe.run(sym)
             torch.cuda.synchronize()
             assert torch.equal(p_offs, c_offs) and torch.equal(p_dense[:stream_bytes], c_dense[:stream_bytes]), \
@@ -652,7 +671,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
             del pipe, p_dense, p_offs
         del c_dense, c_offs, c_scratch
 
-    res = dict(w=w, freq=freq, sym=sym, enc=enc, model=model, kernels=kernels, spec=spec, coder_params=coder_params, source_note=source_note,
+    res = dict(w=w, freq=freq, sym=sym, enc=enc, model=model, kernels=kernels, layout=layout, spec=spec, coder_params=coder_params, source_note=source_note,
                static_model=static_model, elapsed=elapsed, own_elapsed=own_elapsed, enc_ms=enc_ms, dec_ms=dec_ms,
                enc_med=enc_med, dec_med=dec_med, enc_min=float(enc_t.min()), dec_min=float(dec_t.min()), in_bytes=in_bytes,
                stream_bytes=stream_bytes, alg_bytes=alg_bytes, bits_per_symbol=bits_per_symbol, compact_ms=compact_ms,
@@ -671,7 +690,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
 def rooflines(res):
     """roofline objects of one measured workload (encode kernel, decode kernel, encode + compaction)"""
     w, freq = res["w"], res["freq"]
-    tkey, sha = traffic_key(w, freq), csrc_sha(w.coder)
+    tkey, sha = traffic_key(w, freq, res.get("layout", "linear")), csrc_sha(w.coder)
     traffic = load_traffic_note(tkey, sha)
     alg, in_bytes = res["alg_bytes"], res["in_bytes"]
 
@@ -731,7 +750,7 @@ def config_entry(name, res):
         "config": name,
         "workload": f"batched {w.coder}: {w.chunks} independent {w.chunk_len} B chunks ({total / 2**30:.3f} GiB), one lane per "
                     f"chunk, " + res["source_note"],
-        "coder": w.coder, **res["coder_params"], "chunks": w.chunks, "chunk_len": w.chunk_len,
+        "coder": w.coder, **res["coder_params"], "chunks": w.chunks, "chunk_len": w.chunk_len, "slot_layout": res["layout"],
         "steps": res["steps"], "warmup_steps": res["warm_steps"], "warmup_ms": round(res["warm_ms"], 1),
         "value": round(total * res["steps"] / res["elapsed"] / 1e6, 2), "unit": "MB/s",
         "ms_per_step": round(res["elapsed"] / res["steps"] * 1e3, 4),
@@ -1043,6 +1062,7 @@ def main():
                                    f"{chunk_len} B chunks per GPU ({in_bytes / 2**30:.3f} GiB/GPU), one lane per chunk, "
                                    + res["source_note"], "source": w.source if res["static_model"] else "markov1",
                        "coder": w.coder, **res["coder_params"], "chunks_per_gpu": n_chunks, "chunk_len": chunk_len,
+                       "slot_layout": res["layout"],
                        "bits_per_symbol_out": round(res["bits_per_symbol"], 4), "sharding": f"{world} x independent shards"},
             "encode_MBps": round(total_bytes / (enc_ms * 1e-3) / 1e6, 2),
             "decode_MBps": round(total_bytes / (dec_ms * 1e-3) / 1e6, 2),

@@ -289,6 +289,55 @@ int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, co
                            uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
                            uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch, void *stream);
 
+/* ---- wave-striped slots (ABI version 8) --------------------------------------------------------------------------------
+ * A second MEMORY layout for the slots of a batch, written and read by the tuned rANS kernels (and by the tANS models
+ * those kernels serve).  Nothing changes logically: stream c is still nbits[c] bits at bit offset bit_offset[c] =
+ * 8*(c+1)*out_stride - nbits[c] of a buffer of slots of out_stride bytes -- rANSEncoder.encode_block's bits
+ * (scl/compressors/rANS.py:186-210), in the positions the plain entry points put them -- but the 64 slots of a wavefront
+ * are interleaved in 16-byte pieces:
+ *     logical byte A = c*out_stride + b   lives at   (c/64)*64*out_stride + (b/16)*1024 + 16*(c%64) + b%16
+ * so that piece q of the 64 lanes of a wave is one contiguous kilobyte.  A lane then stores 16 bytes at a time where the
+ * linear layout made it buffer whole 128-byte lines (256 B of LDS per lane: two waves per SIMD); the striped encoder runs
+ * four waves per SIMD and stores row by row, 64 adjacent pieces per instruction.  d_out must hold
+ * round_up(n_chunks, 64) * out_stride bytes.  Worth it for batches that fill the chip (>= ~131 072 chunks on MI355X:
+ * 1 GiB headline batch encode 0.55 -> 0.52 ms); smaller batches are faster on the linear entry points.
+ *   scl_*_striped_ok              1 if the striped entry points serve this model (= the tuned kernels do: fast_path with
+ *                                 NUM_BITS_OUT = 1 or in {4, 8, 16}, alphabet <= 256), else 0 -- they then fail with
+ *                                 SCL_E_PARAM, as they do while the calling thread keeps the tuned kernels out;
+ *   scl_*_encode_batch_striped    arguments of scl_rans_encode_batch; out_stride >= scl_*_slot_bytes(chunk_len), < 2^24;
+ *   scl_*_decode_batch_striped    arguments of scl_rans_decode_batch with in_stride (the encoder's out_stride) in place of
+ *                                 in_size_bytes; stream c must lie inside logical slot c;
+ *   scl_streams_compact_striped   scl_streams_compact_at on striped slots: the SAME dense / framed bytes as the linear
+ *                                 path produces (BitArray.tobytes() of every block back to back, or the reference's file
+ *                                 format, encoded_stream.py:150-175) -- the only form the reference ever sees;
+ *   scl_*_kernel_names_striped    scl_*_kernel_names for the striped kernels. */
+int scl_rans_striped_ok(const scl_rans_model *m);
+int scl_tans_striped_ok(const scl_tans_model *m);
+int scl_rans_kernel_names_striped(const scl_rans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
+int scl_tans_kernel_names_striped(const scl_tans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
+int scl_rans_encode_batch_striped(const scl_rans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                  const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                  uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                  uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_rans_decode_batch_striped(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                  const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                  uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                  uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                  uint32_t *d_status, void *stream);
+int scl_tans_encode_batch_striped(const scl_tans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                  const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                  uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                  uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_tans_decode_batch_striped(const scl_tans_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                  const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                  uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                  uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                  uint32_t *d_status, void *stream);
+int scl_streams_compact_striped(const uint8_t *d_in, uint64_t in_stride, const uint64_t *d_bit_offset,
+                                const uint32_t *d_nbits, uint64_t n_chunks, int mode, uint8_t *d_out,
+                                uint64_t out_capacity, uint64_t *d_out_byte_offset, const uint64_t *d_base,
+                                void *d_scratch, void *stream);
+
 /* (ABI version 7) Host-side index of a framed block file held in host memory -- the walk EncodedBlockReader.get_block makes
    one record at a time (encoded_stream.py:196-225) followed by Padder.remove_byte_padding (:48-58), for a whole buffer:
    for every COMPLETE record [u32 BE payload bytes][payload] starting at h_buf[0] writes where its stream starts (bit offset

@@ -98,6 +98,16 @@ _SIGNATURES = {
     "scl_streams_compact_scratch_bytes": (_u64, [_u64]),
     "scl_streams_compact": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp]),
     "scl_streams_compact_at": (_int, [_vp, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp, _vp]),
+    # wave-striped slots (ABI 8): the tuned rANS kernels (and the tANS models they serve) on the interleaved layout
+    "scl_rans_striped_ok": (_int, [_vp]),
+    "scl_tans_striped_ok": (_int, [_vp]),
+    "scl_rans_kernel_names_striped": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
+    "scl_tans_kernel_names_striped": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
+    "scl_rans_encode_batch_striped": (_int, _ENC_BATCH),
+    "scl_rans_decode_batch_striped": (_int, _DEC_BATCH),
+    "scl_tans_encode_batch_striped": (_int, _ENC_BATCH),
+    "scl_tans_decode_batch_striped": (_int, _DEC_BATCH),
+    "scl_streams_compact_striped": (_int, [_vp, _u64, _vp, _vp, _u64, _int, _vp, _u64, _vp, _vp, _vp, _vp]),
     "scl_stream_block_size_host": (_int, [_u8p, _u64, _u32, _u64p]),
     "scl_framed_index_host": (_int, [_vp, _u64, _u32, _u64, _vp, _vp, _vp, _u64p, _u64p]),
     "scl_histogram_u8": (_int, [_vp, _u64, _vp, _vp]),
@@ -124,6 +134,17 @@ for _coder in ("rans", "tans", "range", "aec"):
 for _op, _host in (("encode", _ENC_HOST16), ("decode", _DEC_HOST16)):
     _SIGNATURES[f"scl_aec_{_op}_batch_resume_u16"] = _SIGNATURES[f"scl_aec_{_op}_batch_resume"]
     _SIGNATURES[f"scl_aec_{_op}_host_resume_u16"] = (_int, _host + [_u32p, _u32p])
+
+def any_parameter_forced() -> bool:
+    """are the tuned kernels kept out of the calling thread's batch calls right now?  (``scl_set_any_parameter_kernels``
+    has no getter: set-and-restore, which is thread-local and therefore race-free)"""
+    L = load()
+    prev = L.scl_set_any_parameter_kernels(-1)
+    L.scl_set_any_parameter_kernels(prev)
+    if prev >= 0:
+        return prev == 1
+    return os.environ.get("SCL_ANY_PARAMETER_KERNELS", "")[:1] == "1"
+
 
 _lib = None
 _lock = threading.Lock()

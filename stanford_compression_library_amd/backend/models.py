@@ -47,14 +47,34 @@ class _any_parameter:
 @dataclass
 class EncodedBatch:
     """Device-resident result of a batched encode: ``data`` holds one slot of ``stride`` bytes per chunk;
-    stream c is the ``nbits[c]`` bits starting at absolute bit ``bit_offset[c]`` of ``data``."""
+    stream c is the ``nbits[c]`` bits starting at absolute bit ``bit_offset[c]`` of ``data``.
 
-    data: "torch.Tensor"        # uint8 [n_chunks * stride + 16]
+    ``layout``: ``"linear"`` -- that bit position is a memory position; ``"striped"`` (ABI 8, rANS / tANS tuned kernels) --
+    the same LOGICAL position in wave-striped slots: logical byte ``c * stride + b`` lives at ``(c // 64) * 64 * stride +
+    (b // 16) * 1024 + 16 * (c % 64) + b % 16`` (``linear_data()`` undoes it; :func:`compact` and ``decode_encoded`` read
+    either)."""
+
+    data: "torch.Tensor"        # uint8 [n_chunks * stride + 16]  (striped: round_up(n_chunks, 64) * stride + 16)
     stride: int
     bit_offset: "torch.Tensor"  # uint64 as int64 [n_chunks]
     nbits: "torch.Tensor"       # uint32 as int32 [n_chunks]
     status: "torch.Tensor"      # uint32 as int32 [n_chunks]
     n_chunks: int
+    layout: str = "linear"
+
+    def linear_data(self):
+        """``data`` in the linear layout (a copy for striped batches: a permutation of 16-byte pieces) -- for code that
+        reads slots by ``bit_offset`` (tests, tools); the product path never needs it"""
+        if self.layout == "linear":
+            return self.data
+        n64 = (self.n_chunks + 63) // 64
+        body = self.data[: n64 * 64 * self.stride].view(n64, self.stride // 16, 64, 16).permute(0, 2, 1, 3).reshape(-1)
+        import torch
+
+        return torch.cat([body, self.data.new_zeros(16)])
+
+
+STRIPED_MIN_CHUNKS = 131072  # layout="auto": batches from this size on take the striped kernels (they need the chip full)
 
 
 class _DeviceModel:
@@ -193,21 +213,45 @@ class _DeviceModel:
                 # allocated on torch's current stream, used on another: tell the caching allocator
                 scratch.record_stream(torch.cuda.ExternalStream(int(stream_handle), device=scratch.device))
 
-    def alloc_encoded(self, n_chunks: int, chunk_len: int, device, out_stride: Optional[int] = None) -> EncodedBatch:
-        """Output buffers of a batched encode (reusable across calls of the same shape)."""
+    def striped_ok(self) -> bool:
+        """do the striped entry points (ABI 8) serve this model?  (rANS / tANS models on the tuned kernels)"""
+        fn = getattr(self._L, f"scl_{self._prefix}_striped_ok", None)
+        return bool(fn is not None and self._prefix in ("rans", "tans") and not self.wide and fn(self._h))
+
+    def pick_layout(self, layout: Optional[str], n_chunks: int, any_parameter_kernels: bool = False) -> str:
+        """``"linear"`` / ``"striped"`` as asked (striped must be served), ``"auto"``: striped for batches that fill the
+        chip when the model is served, else linear; ``None`` = linear"""
+        if layout in (None, "linear"):
+            return "linear"
+        can = self.striped_ok() and not any_parameter_kernels and not _lib.any_parameter_forced()
+        if layout == "auto":
+            return "striped" if can and n_chunks >= STRIPED_MIN_CHUNKS else "linear"
+        assert layout == "striped", f"unknown layout {layout!r}"
+        if not can:
+            raise ValueError("layout='striped': this model (or the any-parameter setting) has no striped kernels")
+        return "striped"
+
+    def alloc_encoded(self, n_chunks: int, chunk_len: int, device, out_stride: Optional[int] = None,
+                      layout: Optional[str] = None) -> EncodedBatch:
+        """Output buffers of a batched encode (reusable across calls of the same shape).  ``layout``: see
+        :class:`EncodedBatch` and :meth:`pick_layout`."""
         import torch
 
         stride = int(out_stride or self.slot_bytes(chunk_len))
-        return EncodedBatch(torch.empty(n_chunks * stride + 16, dtype=torch.uint8, device=device), stride,
+        layout = self.pick_layout(layout, n_chunks)
+        slots = (n_chunks + 63) // 64 * 64 if layout == "striped" else n_chunks
+        return EncodedBatch(torch.empty(slots * stride + 16, dtype=torch.uint8, device=device), stride,
                             torch.empty(n_chunks, dtype=torch.int64, device=device),
                             torch.empty(n_chunks, dtype=torch.int32, device=device),
-                            torch.empty(n_chunks, dtype=torch.int32, device=device), n_chunks)
+                            torch.empty(n_chunks, dtype=torch.int32, device=device), n_chunks, layout)
 
     def encode_batch(self, sym, lens=None, out_stride: Optional[int] = None, stream=None,
-                     out: Optional[EncodedBatch] = None, any_parameter_kernels: bool = False) -> EncodedBatch:
+                     out: Optional[EncodedBatch] = None, any_parameter_kernels: bool = False,
+                     layout: Optional[str] = None) -> EncodedBatch:
         """sym: uint8 CUDA tensor [n_chunks, chunk_len] (row-contiguous).  lens: optional int32 [n_chunks].
-        ``out`` reuses buffers from :meth:`alloc_encoded`.  ``any_parameter_kernels`` (tests, stress tools) keeps
-        the tuned kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call)."""
+        ``out`` reuses buffers from :meth:`alloc_encoded` (and fixes the layout).  ``any_parameter_kernels`` (tests,
+        stress tools) keeps the tuned kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call).
+        ``layout``: ``None`` / ``"linear"``, ``"striped"``, ``"auto"`` (:meth:`pick_layout`)."""
         import torch
 
         assert sym.is_cuda and sym.dtype in self._torch_sym_dtypes() and sym.dim() == 2 and sym.stride(1) == 1
@@ -215,8 +259,11 @@ class _DeviceModel:
         dev = sym.device
         # rows that do not start on 16-byte boundaries are re-laid INSIDE the library (RowRelay, csrc/scl_core.hip)
         if out is None:
-            out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride)
+            out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride,
+                                     self.pick_layout(layout, n_chunks, any_parameter_kernels))
         assert out.n_chunks == n_chunks
+        striped = out.layout == "striped"
+        assert not (striped and any_parameter_kernels), "striped slots are written by the tuned kernels only"
         stride, data, bit_off, nbits, status = out.stride, out.data, out.bit_offset, out.nbits, out.status
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         args = [self._h, sym.data_ptr(), sym.stride(0), lens.data_ptr() if lens is not None else None,
@@ -228,8 +275,8 @@ class _DeviceModel:
             self._keep_scratch(st, scratch)
         with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
             # the library launches on the CURRENT device and checks it is the model's
-            rc = self._sym_fn("encode_batch")(*args, st)
-        _lib.check(rc, f"scl_{self._prefix}_encode_batch")
+            rc = self._sym_fn("encode_batch_striped" if striped else "encode_batch")(*args, st)
+        _lib.check(rc, f"scl_{self._prefix}_encode_batch" + ("_striped" if striped else ""))
         return out
 
     def encode_rows_into(self, sym, a: int, b: int, out: EncodedBatch, stream_handle: int):
@@ -240,6 +287,8 @@ class _DeviceModel:
 
         n_rows, chunk_len = sym.shape
         assert 0 <= a <= b <= n_rows == out.n_chunks and sym.stride(1) == 1
+        striped = out.layout == "striped"
+        assert not striped or a % 64 == 0, "striped slots: a sub-batch starts on a multiple of 64 chunks"
         assert sym.stride(0) % 16 == 0 and sym.data_ptr() % 16 == 0, "rows must start on 16-byte boundaries"
         assert not self.wide, "the overlapped pipeline carries uint8 symbols"
         args = [self._h, sym.data_ptr() + a * sym.stride(0), sym.stride(0), None, chunk_len, b - a,
@@ -250,8 +299,8 @@ class _DeviceModel:
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
             self._keep_scratch(("rows", a, n_rows, int(stream_handle or 0)), scratch)
         with torch.cuda.device(sym.device):
-            rc = self._fn("encode_batch")(*args, stream_handle)
-        _lib.check(rc, f"scl_{self._prefix}_encode_batch")
+            rc = self._fn("encode_batch_striped" if striped else "encode_batch")(*args, stream_handle)
+        _lib.check(rc, f"scl_{self._prefix}_encode_batch" + ("_striped" if striped else ""))
 
     def alloc_decoded(self, n_chunks: int, chunk_cap: int, device):
         import torch
@@ -262,11 +311,18 @@ class _DeviceModel:
                 torch.empty(n_chunks, dtype=torch.int32, device=device),
                 torch.empty(n_chunks, dtype=torch.int32, device=device))
 
+    def decode_encoded(self, enc: EncodedBatch, chunk_cap: int, stream=None, out=None, any_parameter_kernels: bool = False):
+        """:meth:`decode_batch` of an :class:`EncodedBatch` in whichever layout it has"""
+        return self.decode_batch(enc.data, enc.bit_offset, enc.nbits, chunk_cap, stream=stream, out=out,
+                                 any_parameter_kernels=any_parameter_kernels,
+                                 striped_stride=enc.stride if enc.layout == "striped" else None)
+
     def decode_batch(self, data, bit_offset, nbits, chunk_cap: int, stream=None, out=None,
-                     any_parameter_kernels: bool = False):
+                     any_parameter_kernels: bool = False, striped_stride: Optional[int] = None):
         """-> (sym uint8 [n_chunks, chunk_cap], lens int32, consumed int32, status int32) on the device.
         ``out`` reuses buffers from :meth:`alloc_decoded`.  ``any_parameter_kernels`` (tests) keeps the tuned
-        kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call)."""
+        kernels out (``SCL_ANY_PARAMETER_KERNELS=1`` for the duration of the call).  ``striped_stride``: ``data`` holds
+        wave-striped slots of that stride (stream c inside logical slot c; :class:`EncodedBatch`)."""
         import torch
 
         assert data.is_cuda and data.dtype == torch.uint8
@@ -275,16 +331,26 @@ class _DeviceModel:
         sym, lens, used, status = out if out is not None else self.alloc_decoded(n_chunks, chunk_cap, dev)
         out_stride = sym.stride(0)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        args = [self._h, data.data_ptr(), data.numel(), bit_offset.data_ptr(), nbits.data_ptr(), n_chunks,
+        striped = striped_stride is not None
+        assert not (striped and any_parameter_kernels), "striped slots are read by the tuned kernels only"
+        args = [self._h, data.data_ptr(), int(striped_stride) if striped else data.numel(), bit_offset.data_ptr(),
+                nbits.data_ptr(), n_chunks,
                 sym.data_ptr(), out_stride, int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr()]
         if self._needs_scratch:
             scratch, nbytes = self._scratch(n_chunks, dev)
             args += [scratch.data_ptr() if scratch is not None else None, nbytes]
             self._keep_scratch(st, scratch)
         with torch.cuda.device(dev), _any_parameter(any_parameter_kernels):
-            rc = self._sym_fn("decode_batch")(*args, st)
-        _lib.check(rc, f"scl_{self._prefix}_decode_batch")
+            rc = self._sym_fn("decode_batch_striped" if striped else "decode_batch")(*args, st)
+        _lib.check(rc, f"scl_{self._prefix}_decode_batch" + ("_striped" if striped else ""))
         return sym[:, :chunk_cap], lens, used, status
+
+    def kernel_names(self, n_chunks: int, layout: str = "linear"):
+        """(encode kernel, decode kernel) a batch of that size runs, as rocprofv3 prints them (rANS / tANS models)"""
+        enc, dec = C.create_string_buffer(160), C.create_string_buffer(160)
+        fn = f"scl_{self._prefix}_kernel_names" + ("_striped" if layout == "striped" else "")
+        _lib.check(getattr(self._L, fn)(self._h, int(n_chunks), enc, dec, 160), fn)
+        return enc.value.decode(), dec.value.decode()
 
 
 class RansModel(_DeviceModel):
@@ -484,10 +550,23 @@ def compact_into(enc: EncodedBatch, out, offsets, scratch, framed: bool = False,
     dev = enc.data.device
     st = stream if stream is not None else torch.cuda.current_stream(dev)
     with torch.cuda.device(dev):
-        rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), enc.n_chunks,
-                                   _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), out.numel(),
-                                   offsets.data_ptr(), scratch.data_ptr(), st.cuda_stream)
+        rc = _compact_call(L, enc, 0, enc.n_chunks, _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(),
+                           out.numel(), offsets.data_ptr(), None, scratch.data_ptr(), st.cuda_stream)
     _lib.check(rc, "scl_streams_compact")
+
+
+def _compact_call(L, enc: EncodedBatch, a: int, b: int, mode: int, out_ptr: int, out_cap: int, offsets_ptr: int, base_ptr,
+                  scratch_ptr: int, stream_handle):
+    """chunks a..b of ``enc`` through scl_streams_compact_at or, for striped batches, scl_streams_compact_striped (a must
+    then be a multiple of 64: a sub-batch starts with a whole wave)"""
+    if enc.layout == "striped":
+        assert a % 64 == 0
+        return L.scl_streams_compact_striped(enc.data.data_ptr() + a * enc.stride, enc.stride,
+                                             enc.bit_offset.data_ptr() + 8 * a, enc.nbits.data_ptr() + 4 * a, b - a, mode,
+                                             out_ptr, out_cap, offsets_ptr, base_ptr, scratch_ptr, stream_handle)
+    return L.scl_streams_compact_at(enc.data.data_ptr() + a * enc.stride, enc.bit_offset.data_ptr() + 8 * a,
+                                    enc.nbits.data_ptr() + 4 * a, b - a, mode, out_ptr, out_cap, offsets_ptr, base_ptr,
+                                    scratch_ptr, stream_handle)
 
 
 def compact_capacity(n_chunks: int, stride: int, framed: bool = False) -> int:
@@ -519,9 +598,8 @@ def compact(enc: EncodedBatch, framed: bool = False, stream=None):
     offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.scl_streams_compact_scratch_bytes(n)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = L.scl_streams_compact(enc.data.data_ptr(), enc.bit_offset.data_ptr(), enc.nbits.data_ptr(), n,
-                                   _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), cap,
-                                   offsets.data_ptr(), scratch.data_ptr(), tstream.cuda_stream)
+        rc = _compact_call(L, enc, 0, n, _lib.COMPACT_FRAMED if framed else _lib.COMPACT_DENSE, out.data_ptr(), cap,
+                           offsets.data_ptr(), None, scratch.data_ptr(), tstream.cuda_stream)
     _lib.check(rc, "scl_streams_compact")
     tstream.synchronize()  # the stream the kernels were queued on: results readable, scratch reusable on return
     return out, offsets
@@ -580,14 +658,17 @@ class DensePipeline:
     Buffers are owned by the object (worst-case sizes, reused across calls); results are valid once the caller's current
     stream has passed the call.  Static-model coders only (rANS / tANS / range / FixedFreqModel: no per-call scratch)."""
 
-    def __init__(self, model, n_chunks: int, chunk_len: int, device, n_sub: int = 2, framed: bool = False):
+    def __init__(self, model, n_chunks: int, chunk_len: int, device, n_sub: int = 2, framed: bool = False,
+                 layout: Optional[str] = None):
         import torch
 
         assert not model._needs_scratch and not model.wide
         self.model, self.n_chunks, self.chunk_len, self.framed = model, int(n_chunks), int(chunk_len), bool(framed)
         n_sub = max(1, min(int(n_sub), self.n_chunks))
         self.bounds = [self.n_chunks * i // n_sub for i in range(n_sub + 1)]
-        self.enc = model.alloc_encoded(self.n_chunks, self.chunk_len, device)
+        self.enc = model.alloc_encoded(self.n_chunks, self.chunk_len, device, layout=layout)
+        if self.enc.layout == "striped":  # a sub-batch starts with a whole wave of 64 slots
+            self.bounds = sorted({min(self.n_chunks, (b + 63) // 64 * 64) for b in self.bounds[:-1]} | {self.n_chunks})
         self.dense = torch.empty(compact_capacity(self.n_chunks, self.enc.stride, framed), dtype=torch.uint8, device=device)
         self.offsets = torch.empty(self.n_chunks + 1, dtype=torch.int64, device=device)
         per = max(b - a for a, b in zip(self.bounds, self.bounds[1:]))
@@ -613,9 +694,8 @@ class DensePipeline:
                 ev = torch.cuda.Event()
                 ev.record(self.s_enc)
                 self.s_cmp.wait_event(ev)
-                rc = L.scl_streams_compact_at(
-                    enc.data.data_ptr() + a * stride, enc.bit_offset.data_ptr() + 8 * a, enc.nbits.data_ptr() + 4 * a, b - a,
-                    mode, self.dense.data_ptr(), self.dense.numel(), self.offsets.data_ptr() + 8 * a,
+                rc = _compact_call(
+                    L, enc, a, b, mode, self.dense.data_ptr(), self.dense.numel(), self.offsets.data_ptr() + 8 * a,
                     (self.offsets.data_ptr() + 8 * a) if i else None,  # starts where the previous sub-batch ended
                     self.scratch.data_ptr() + self.scr * i, self.s_cmp.cuda_stream)
                 _lib.check(rc, "scl_streams_compact_at")

@@ -177,6 +177,7 @@ struct AnsBackWriterL {
     static constexpr u32 FLUSH_MASK = 3;   // the encoder's flush points: every (FLUSH_MASK + 1) x 16 symbols
     static constexpr u32 FLUSH_PHASE = 1;  // ... after block 1 (mod 4) of a line
     static constexpr u32 WG_PER_CU = 2;    // 64 KiB of rings + the 4 KiB table per 256 lanes
+    static constexpr bool STRIPED = false;
     static constexpr u32 LANE_BYTES = 256;                   // one 256-byte ring per lane, 256-byte aligned
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;  // placed at LDS offset 0 of the workgroup
     u32 hi, lo;   // the window
@@ -332,6 +333,7 @@ struct AnsBackWriterS {
     static constexpr u32 FLUSH_MASK = 1;
     static constexpr u32 FLUSH_PHASE = 0;  // after blocks 0, 2, 4, 6 of a line: none just before its end (see the kernel)
     static constexpr u32 WG_PER_CU = 3;
+    static constexpr bool STRIPED = false;
     static constexpr u32 LANE_BYTES = 192;
     static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;
     u32 hi, lo;   // the window
@@ -450,6 +452,146 @@ struct AnsBackWriterS {
         const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
         if (n) end32[-(i64)np - 1] = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
         return (u64)(((goff0 - goff) >> 2) + np) * 32 + n;
+    }
+};
+
+// Round-6 back writer for WAVE-STRIPED slots: four workgroups per CU.
+//
+// What held the L / S writers at two or three waves per SIMD is the line buffer: a lane that owns a contiguous slot must
+// store whole 128-byte lines (anything smaller reaches memory as its own partial-line request: rounds 1-3), so it buffers
+// a whole line while the next one fills -- 192 to 256 bytes of LDS per lane.  In a STRIPED slot the 64 streams of a wave
+// are interleaved at 16-byte granularity:
+//     byte b of the logical slot of lane l (stride S, stream ending at S)  ->  wave_slot + (b / 16) * 1024 + 16 l + b % 16
+// i.e. the 16-byte piece q of every lane forms ONE contiguous kilobyte ("row" q): eight neighbouring lanes share a
+// 128-byte line.  A lane then stores a piece as soon as it has one (a 16-byte store whose neighbours, a few symbols apart
+// in time, complete the line in L2), buffers 16 bytes instead of 128, and the ring shrinks to 128 bytes per lane: 32 KiB +
+// the 4 KiB table per workgroup = four workgroups per CU, four waves per SIMD.  Nothing is cooperative, so ragged
+// batches and partial waves take the same path.  The logical position of every bit is what it was -- `bit_offset` /
+// `nbits` keep their meaning -- only the mapping to memory changes (scl_stripe_byte below; the decoder's reader and
+// scl_streams_compact undo it).
+//   * bit window, check(): as AnsBackWriterL (the asm block differs in the ring constants only);
+//   * ring: 32 words per lane, [thread][word], words in MEMORY order inside 16-byte pieces, rotated by 16 * (lane mod 8)
+//     bytes against lockstep tables; flush points 32 symbols apart (<= 13 new words on top of <= 3 pending + 16 to spare);
+//   * flush(): rounds -- in each round every lane that holds a complete piece reads it (one ds_read_b128) and stores it at
+//     its own row (the lanes of a wave are within a row or two of each other: the 64 pieces of a round fall into two or
+//     three rows, contiguous where neighbours agree).
+__device__ __forceinline__ u64 scl_stripe_byte(u64 logical_byte, u64 stride) {
+    // logical byte address in a batch of slots of `stride` bytes (a multiple of 16) -> physical byte address
+    const u64 slot = logical_byte / stride, b = logical_byte - slot * stride;
+    return (slot >> 6) * (stride << 6) + (b >> 4) * 1024u + ((slot & 63u) << 4) + (b & 15u);
+}
+template <int THREADS>
+struct AnsBackWriterT {
+    static constexpr u32 FLUSH_MASK = 1;   // the encoder's flush points: every 32 symbols
+    static constexpr u32 FLUSH_PHASE = 0;  // after blocks 0, 2, 4, 6 of a line: none just before its end (see the kernel)
+    static constexpr u32 WG_PER_CU = 4;    // 32 KiB of rings + the 4 KiB table per 256 lanes
+    static constexpr u32 LANE_BYTES = 128;
+    static constexpr u32 RING_BYTES = THREADS * LANE_BYTES;
+    static constexpr bool STRIPED = true;
+    u32 hi, lo;   // the window
+    u32 room;     // 32 - (number of pending bits): a push that BORROWS completed a word
+    u32 wa;       // LDS byte address (from the ring base) of the word that completes next: base | offset 0..124
+    u32 th4;      // ring offset of the FIRST word (highest address) of the oldest unflushed piece (= 12 mod 16)
+    u32 base;     // tid * LANE_BYTES
+    u32 goff;     // byte offset (from the workgroup's output base) of this lane's next piece
+    u32 goff0;    // ... of its first piece (the last 16 bytes of its logical slot)
+    u32 np;       // pieces this lane has stored
+    u32 rs;       // rows the whole wave has stored (the same value in every lane; np >= rs)
+
+    __device__ __forceinline__ u32 pend4() const { return (th4 - wa) & 127u; }  // 4 * completed words not yet stored
+
+    // out_stride: bytes per logical slot (a multiple of 16; 256 lanes * out_stride < 2^32)
+    __device__ __forceinline__ void init(u32 tid, u32 out_stride) {
+        hi = lo = 0;
+        room = 32;
+        base = tid * LANE_BYTES;
+        th4 = (124u + 16u * (tid & 7u)) & 127u;
+        wa = base | th4;
+        goff = goff0 = ((tid >> 6) + 1u) * (out_stride << 6) - 1024u + ((tid & 63u) << 4);
+        np = rs = 0;
+    }
+    __device__ __forceinline__ void push(u32 v, u32 k) {  // the low k bits of v go in front of the stream; k < 32
+        lo = __builtin_amdgcn_alignbit(hi, lo, k);
+        hi = __builtin_amdgcn_alignbit(v, hi, k);
+    }
+    __device__ __forceinline__ void push_hi(u32 v, u32 k) { hi = __builtin_amdgcn_alignbit(v, hi, k); }  // see AnsBackWriterL
+    __device__ __forceinline__ void fold_lo(u32 hi_before, u32 bits) { lo = __builtin_amdgcn_alignbit(hi_before, lo, bits); }
+    template <u32 RING_OFF>
+    __device__ __forceinline__ void check(char *lds, u32 bits) {  // as AnsBackWriterL::check, by hand for the same reason
+        u32 w, t;
+        u64 sv;
+        asm volatile(
+            "v_sub_co_u32 %[room], vcc, %[room], %[bits]\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "v_alignbit_b32 %[w], %[hi], %[lo], %[room]\n\t"
+            "v_add_u32 %[t], 0x7c, %[wa]\n\t"
+            "v_perm_b32 %[w], 0, %[w], %[sel]\n\t"
+            "v_add_u32 %[room], 32, %[room]\n\t"
+            "ds_write_b32 %[wa], %[w] offset:%[off]\n\t"
+            "v_and_or_b32 %[wa], %[t], %[m127], %[base]\n\t"
+            "s_or_b64 exec, exec, %[sv]"
+            : [room] "+v"(room), [wa] "+v"(wa), [w] "=&v"(w), [t] "=&v"(t), [sv] "=&s"(sv)
+            : [bits] "v"(bits), [hi] "v"(hi), [lo] "v"(lo), [sel] "s"(0x00010203u), [m127] "s"(127u), [base] "v"(base),
+              [off] "i"(RING_OFF)
+            : "vcc", "memory");
+        (void)lds;
+    }
+    template <u32 RING_OFF>
+    __device__ __forceinline__ void put32(char *lds, u32 v, u32 w) {  // any w <= 32 (header fields)
+        if (w > 16) {
+            push(v, 16);
+            check<RING_OFF>(lds, 16);
+            push(v >> 16, w - 16);
+            check<RING_OFF>(lds, w - 16);
+        } else {
+            push(v, w);
+            check<RING_OFF>(lds, w);
+        }
+    }
+    __device__ __forceinline__ void store_piece(char *lds, u8 *wg_out) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(lds + base + ((th4 - 12u) & 127u));
+        {
+            typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
+            const u32x4_nt t = {q.x, q.y, q.z, q.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(wg_out + goff));
+        }
+        goff -= 1024u;
+        th4 = (th4 - 16u) & 127u;
+        np += 1u;
+    }
+    // Flush point (any subset of the wave may call; the lanes present act together).  Lanes complete their pieces at
+    // data-dependent times; a piece stored the moment it is complete makes every 128-byte line arrive in two or three
+    // partial writes (measured: +0.13 ms per GiB batch, worse than the L writer).  So the wave stores ROW BY ROW: row rs goes
+    // out when every lane present has it complete (or has already stored it) -- one instruction, 64 adjacent pieces, eight
+    // whole lines -- and the ring absorbs the lanes' drift (a lane may hold up to GUARD bytes of complete words when it
+    // leaves; beyond that it stores its own oldest pieces, partial lines, rare -- the ring must never hold 32 words).
+    // guard: 4 * (31 - the most words 32 symbols can complete): 72 for <= 13 bits per symbol, 60 for <= 16
+    __device__ __forceinline__ void flush(char *lds, u8 *wg_out, u32 guard) {
+        for (;;) {
+            const bool has = pend4() >= 16u;
+            const bool ready = has || np > rs;
+            if (__builtin_amdgcn_ballot_w64(ready) != __builtin_amdgcn_ballot_w64(true)) break;
+            if (np == rs) store_piece(lds, wg_out);
+            rs += 1u;
+        }
+        while (pend4() > guard) store_piece(lds, wg_out);
+    }
+    __device__ __forceinline__ void flush_all(char *lds, u8 *wg_out) {  // per lane
+        while (pend4() >= 16u) store_piece(lds, wg_out);
+    }
+    __device__ __forceinline__ u64 finish(char *lds, u8 *wg_out) {  // per lane; returns the stream length in bits
+        flush_all(lds, wg_out);
+        u8 *piece = wg_out + goff;           // the piece that is still filling: its words go in from the top
+        const u32 nw = pend4() >> 2;         // < 4 now
+        u32 a = th4;
+        for (u32 j = 0; j < nw; ++j) {
+            *reinterpret_cast<u32 *>(piece + 12u - 4u * j) = *reinterpret_cast<const u32 *>(lds + base + a);
+            a = (a - 4u) & 127u;
+        }
+        const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
+        // (nw <= 3; with n != 0 and nw == 3 the word lands at piece + 0)
+        if (n) *reinterpret_cast<u32 *>(piece + 12u - 4u * nw) = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
+        return (u64)(np * 4u + nw) * 32 + n;
     }
 };
 
@@ -818,6 +960,100 @@ struct AnsBitReaderW {
         N -= nb;
         // one v_lshl_add; written out because the compiler re-associates P into (initial P) + (running sum << RSH), an add
         // more per pair
+        asm("v_lshl_add_u32 %0, %1, %2, %0" : "+v"(P) : "v"(nb), "n"(RSH));
+    }
+    __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32
+        const u32 v = look(lds) >> (32 - w);
+        advance(lds, w);
+        return v;
+    }
+};
+
+// Round-6 reader for WAVE-STRIPED slots (the layout AnsBackWriterT writes; scl_stripe_byte).  Same windowless look() /
+// advance() as AnsBitReaderW over the same [word][thread] ring of 32 words -- what changes is the refill: the unit is the
+// 16-byte PIECE, not the 128-byte line.  Piece q of lane l lives at wave_slot + 1024 q + 16 l, so when the lanes of a wave
+// fetch "their next piece" the addresses of neighbouring lanes are adjacent -- lanes within the same row read ONE
+// contiguous run -- where the linear layout made every lane's load touch a different line (64 lines per instruction).
+// Refill point (every 32 symbols of <= 13 bits, like AnsBitReaderW): first the pieces requested at the PREVIOUS refill
+// point enter the ring (they have had 32 symbols' time to arrive), then every lane requests as many pieces as its ring
+// will have room for: free = 32 - ahead words -> free / 4 pieces, at most four.  Level: after the arrivals a lane holds
+// >= 15 words (13 for the next 32 symbols + the two around the position) because at the previous point it requested
+// floor(free / 4) pieces, i.e. ahead + 4 * requested >= 29.
+// Loads never leave the lane's slot: the offset of the next piece is clamped to the last piece (a stream that claims more
+// bits than it has re-reads its tail and is flagged TRUNCATED by the caller's length check).
+template <int THREADS>
+struct AnsBitReaderT {
+    static constexpr u32 RING_BYTES = 32u * THREADS * 4u;
+    static constexpr u32 ROW = THREADS * 4u;
+    static constexpr u32 RSH = THREADS == 1024 ? 7u : (THREADS == 512 ? 6u : (THREADS == 256 ? 5u : 4u));  // log2(ROW) - 5
+    static constexpr u32 ROWMASK = 31u * ROW;
+    static_assert((32u << RSH) == ROW, "THREADS must be 128, 256, 512 or 1024");
+    const u8 *wbase;  // the wave's striped slot + 16 * lane
+    u32 goff;         // byte offset (from wbase) of the next piece to request
+    u32 glast;        // ... of the lane's last piece
+    uint4 pf[4];      // pieces requested at the previous refill point
+    u32 npf;          // how many of them
+    u32 wa;           // LDS byte address of the ring row filled next (a multiple of four rows | col)
+    u32 N, P;         // as AnsBitReaderW
+    u32 col;          // tid * 4
+    u32 rowA;         // LDS byte address of the first word the last look() read
+    u32 start;        // bit position at init (inside the first piece loaded: < 128)
+
+    __device__ __forceinline__ uint4 fetch() {
+        const uint4 q = *reinterpret_cast<const uint4 *>(wbase + goff);
+        goff = min(goff + 1024u, glast);
+        return q;
+    }
+    __device__ __forceinline__ void push_piece(char *lds, const uint4 &q) {
+        char *r = lds + wa;
+        *reinterpret_cast<u32 *>(r) = __builtin_bswap32(q.x);
+        *reinterpret_cast<u32 *>(r + ROW) = __builtin_bswap32(q.y);
+        *reinterpret_cast<u32 *>(r + 2 * ROW) = __builtin_bswap32(q.z);
+        *reinterpret_cast<u32 *>(r + 3 * ROW) = __builtin_bswap32(q.w);
+        wa = (wa + 4 * ROW) & (RING_BYTES - 1);
+    }
+    __device__ __forceinline__ u32 ahead_m1() const { return (wa - rowA - ROW) & (RING_BYTES - 1); }
+    // call at least every 32 symbols of <= 13 bits
+    __device__ __forceinline__ void maybe_refill(char *lds) {
+#pragma unroll
+        for (u32 r = 0; r < 4; ++r)
+            if (npf > r) push_piece(lds, pf[r]);
+        npf = min((31u - (ahead_m1() >> (RSH + 5u))) >> 2, 4u);  // free words / 4 (<= 4 anyway: >= 15 words are ahead here)
+#pragma unroll
+        for (u32 r = 0; r < 4; ++r)
+            if (npf > r) pf[r] = fetch();
+    }
+    // in: the batch's output buffer; stride: bytes per logical slot (a multiple of 16); c: this lane's chunk; bit_off: the
+    // stream's LOGICAL bit offset (inside slot c)
+    __device__ __forceinline__ void init(const u8 *in, u64 stride, u64 c, u64 bit_off, char *lds, u32 tid) {
+        const u32 rel = (u32)(bit_off - c * stride * 8);  // < 2^32: slots are below 512 MiB
+        wbase = in + (c >> 6) * (stride << 6) + ((c & 63u) << 4);
+        glast = (u32)stride * 64u - 1024u;
+        goff = min((rel >> 7) * 1024u, glast);
+        col = tid * 4;
+        wa = col;
+        uint4 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = fetch();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) push_piece(lds, q[i]);  // wa is back at row 0: the ring is full
+        npf = 0;
+        start = rel & 127u;
+        N = 0u - start;
+        P = (start - 1u) << RSH;
+        rowA = ((start >> 5) * ROW) | col;
+    }
+    __device__ __forceinline__ u32 consumed() const { return (0u - N) - start; }
+    __device__ __forceinline__ u32 look(const char *lds) {
+        const u32 a = (P & ROWMASK) | col;
+        const u32 b = ((P + ROW) & ROWMASK) | col;
+        rowA = a;
+        const u32 A = *reinterpret_cast<const u32 *>(lds + a);
+        const u32 B = *reinterpret_cast<const u32 *>(lds + b);
+        return __builtin_amdgcn_alignbit(A, B, N);
+    }
+    __device__ __forceinline__ void advance(const char *, u32 nb) {
+        N -= nb;
         asm("v_lshl_add_u32 %0, %1, %2, %0" : "+v"(P) : "v"(nb), "n"(RSH));
     }
     __device__ __forceinline__ u32 get(const char *lds, u32 w) {  // 1 <= w <= 32

@@ -15,7 +15,7 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 #define SCL_WAVE 64
-#define SCL_ABI_VERSION 7
+#define SCL_ABI_VERSION 8
 #define SCL_MAX_ALPHABET 65536u  // uint16 symbol indices (the *_u16 entry points); the uint8 entry points stop at 256
 
 // ---- host-side error plumbing ------------------------------------------------------------------

@@ -343,6 +343,151 @@ __global__ void __launch_bounds__(256) cp_copy(const u8 *__restrict__ in, const 
     }
 }
 
+// pass 4 for WAVE-STRIPED slots (ABI version 8; scl_ans_fast_io.h: byte b of the logical slot of stream c lives at
+// (c / 64) * 64 * stride + (b / 16) * 1024 + 16 * (c % 64) + b % 16): the same record, byte for byte, as cp_copy writes
+// from linear slots.  A destination block's 160 source bits are five consecutive logical words = parts of two consecutive 16-byte pieces;
+// 128 k bits further is exactly one piece further, so the offset of the first word inside its piece is the same for every
+// block of a stream: two 16-byte loads per block and a choice of five words out of eight.
+struct StripedSrc {
+    const u32 *w32;  // word 0 of this stream's logical slot (piece 0)
+    u64 end;         // first bit after the stream, relative to the slot start
+    __device__ __forceinline__ u32 word_at(u64 idx) const {  // big-endian logical word idx; zero past the stream's last word
+        if (idx * 32 >= end) return 0;
+        return scl_bswap32(w32[(idx >> 2) * 256 + (idx & 3)]);
+    }
+    __device__ __forceinline__ u32 peek_at(u64 p, u32 w) const {  // bits [p, p + w), zero at or past `end`; w <= 32
+        if (w == 0) return 0;
+        const u64 idx = p >> 5;
+        const u32 sh = (u32)(p & 31);
+        const u64 win = ((u64)word_at(idx) << 32) | (sh + w > 32 ? word_at(idx + 1) : 0u);
+        u32 v = (u32)((win >> (64 - sh - w)) & (w == 32 ? 0xFFFFFFFFull : ((1ull << w) - 1)));
+        if (p + w > end) {
+            const u64 over = p + w - end;
+            v = (over >= w) ? 0u : (u32)(((u64)v >> over) << over);
+        }
+        return v;
+    }
+};
+__device__ __forceinline__ u32 cps_payload_bits(const StripedSrc &r, u64 pos, u64 q, u32 w_bytes, u32 lead, u32 pad) {
+    const u64 b0 = 8 * q;
+    const u32 wb = 8 * w_bytes;
+    if (b0 >= lead) return r.peek_at(pos + b0 - lead, wb);
+    u32 v = 0;
+    if (b0 + wb > lead) v = r.peek_at(pos, (u32)(b0 + wb - lead));
+    if (q == 0) v |= pad << (wb - 3);
+    return v;
+}
+// Work split: one wavefront = the EIGHT streams of a lane group (c = 8 g .. 8 g + 7: the lanes that share every 128-byte
+// line of their rows).  Lane (k, i) = (lane & 7, lane >> 3) works for stream k on the piece rows r0 + i, r0 + i + 8, ...:
+// a load instruction then reads 8 rows x 8 adjacent pieces = eight WHOLE lines, and the eight lanes of a stream write
+// eight consecutive 16-byte blocks of its record (a 128-byte run) per store instruction.  (One wave per stream, as
+// cp_copy has it, made every load instruction touch 64 lines, 16 bytes of each: 0.80 ms per GiB batch against 0.38.)
+#define CPS_THREADS 256
+__global__ void __launch_bounds__(CPS_THREADS) cp_copy_striped(const u8 *__restrict__ in, u64 stride,
+                                                               const u64 *__restrict__ bit_off,
+                                                               const u32 *__restrict__ nbits, u64 n, int mode,
+                                                               u8 *__restrict__ out, u64 out_capacity,
+                                                               const u64 *__restrict__ rec_off) {
+    const u32 lane = threadIdx.x & (SCL_WAVE - 1);
+    const u32 k = lane & 7u, i = lane >> 3;
+    const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / SCL_WAVE;  // lane group
+    const u64 c = g * 8 + k;
+    const bool live = c < n && rec_off[min(c + 1, n)] <= out_capacity;  // caller sees the required size in rec_off[n]
+    // ---- this lane's stream (the eight lanes of a stream compute the same values) -----------------------------------
+    i64 k_first = 1, k_last = 0, rowbase = 0;
+    u32 sh = 0, o = 0;
+    u8 *dst_al = nullptr;
+    const u8 *slot = in + ((c >> 6) * (stride << 6) + ((c & 63u) << 4));
+    if (live) {
+        const u64 o0 = rec_off[c], o1 = rec_off[c + 1];
+        const u32 nb = nbits[c];
+        const u64 pos = bit_off[c] - c * stride * 8;  // the stream's first bit inside its logical slot
+        StripedSrc r;
+        r.w32 = reinterpret_cast<const u32 *>(slot);
+        r.end = pos + nb;
+        u8 *dst = out + o0;
+        u64 rec_bytes = o1 - o0;
+        u32 lead = 0, pad = 0;
+        if (mode == SCL_COMPACT_FRAMED) {
+            const u32 payload = (u32)(rec_bytes - 4);
+            pad = payload * 8 - 3 - nb;
+            lead = 3 + pad;
+            if (i == 0) {
+                dst[0] = (u8)(payload >> 24);
+                dst[1] = (u8)(payload >> 16);
+                dst[2] = (u8)(payload >> 8);
+                dst[3] = (u8)payload;
+            }
+            dst += 4;
+            rec_bytes -= 4;
+        }
+        const u32 a = (u32)(reinterpret_cast<uintptr_t>(dst) & 15);
+        dst_al = dst - a;  // block kk lives at dst_al + 16 kk
+        const i64 src_base = (i64)pos - (i64)lead - 8 * (i64)a;  // source bit of byte 0 of block 0 (may lie before the stream)
+        const i64 src_al = src_base & ~31ll;
+        sh = (u32)src_base & 31u;
+        const i64 stream_end = (i64)pos + (i64)nb;
+        // interior blocks k_first .. k_last: inside the record, past the lead bits, five source words inside the stream
+        k_first = max((i64)((a + 15) / 16), ((i64)lead + 8 * (i64)a + 127) / 128);
+        k_last = (i64)((a + rec_bytes) / 16) - 1;
+        {
+            const i64 room = stream_end - 160 - src_al;
+            const i64 k_src = room >= 0 ? room / 128 : -1;
+            if (k_src < k_last) k_last = k_src;
+        }
+        const bool any_fast = k_last >= k_first;
+        const u64 q_lo = any_fast ? (u64)(16 * k_first - a) : rec_bytes;  // payload bytes [0, q_lo) and [q_hi, rec_bytes)
+        const u64 q_hi = any_fast ? (u64)(16 * (k_last + 1) - a) : rec_bytes;  // are the edges: one byte per lane of the stream
+        for (u64 q = i; q < q_lo; q += 8) dst[q] = (u8)cps_payload_bits(r, pos, q, 1, lead, pad);
+        for (u64 q = q_hi + i; q < rec_bytes; q += 8) dst[q] = (u8)cps_payload_bits(r, pos, q, 1, lead, pad);
+        // word (src_al >> 5) + 4 kk is the first of block kk's five: piece rowbase + kk, word offset o in it
+        const i64 w00 = src_al >> 5;  // may be negative only when no interior block exists
+        o = (u32)(w00 & 3);
+        rowbase = w00 >> 2;
+        if (!any_fast) k_first = 1, k_last = 0;
+    }
+    // ---- every stream walks ITS OWN blocks in groups of eight that start on a 128-byte line of the destination: lane (k, i)
+    // takes block kk0 + 8 t + i of stream k, so the eight lanes of a stream store one whole, aligned line per instruction
+    const i64 kk0 = live ? (k_first - (i64)(((reinterpret_cast<uintptr_t>(dst_al) >> 4) + (u64)k_first) & 7u)) : 0;
+    i64 trips = (live && k_last >= k_first) ? (k_last - kk0) / 8 + 1 : 0;
+    for (int d = 1; d < 8; d <<= 1) trips = max(trips, (i64)__shfl_xor((long long)trips, d));
+    const uint4 *piece = reinterpret_cast<const uint4 *>(slot);
+    for (i64 t0 = 0; t0 < trips; t0 += 4) {
+        uint4 pa[4], pb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 kk = kk0 + 8 * (t0 + j) + i, row = rowbase + kk;
+            if (kk >= k_first && kk <= k_last) {
+                pa[j] = piece[row * 64];
+                pb[j] = piece[(row + 1) * 64];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 kk = kk0 + 8 * (t0 + j) + i;
+            if (kk >= k_first && kk <= k_last) {
+                const u32 w8[8] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w, pb[j].x, pb[j].y, pb[j].z, pb[j].w};
+                u32 b[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {  // b[t] = word o + t of the eight (o differs from stream to stream)
+                    const u32 lo2 = (o & 1u) ? w8[t + 1] : w8[t];
+                    const u32 hi2 = (o & 1u) ? w8[t + 3] : w8[t + 2];
+                    b[t] = scl_bswap32((o & 2u) ? hi2 : lo2);
+                }
+                uint4 v;  // (x << sh) | (y >> (32 - sh)); v_alignbit takes its shift modulo 32, hence the select
+                v.x = sh ? __builtin_amdgcn_alignbit(b[0], b[1], 32 - sh) : b[0];
+                v.y = sh ? __builtin_amdgcn_alignbit(b[1], b[2], 32 - sh) : b[1];
+                v.z = sh ? __builtin_amdgcn_alignbit(b[2], b[3], 32 - sh) : b[2];
+                v.w = sh ? __builtin_amdgcn_alignbit(b[3], b[4], 32 - sh) : b[3];
+                v.x = scl_bswap32(v.x), v.y = scl_bswap32(v.y), v.z = scl_bswap32(v.z), v.w = scl_bswap32(v.w);
+                typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
+                const u32x4_nt t4 = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(t4, reinterpret_cast<u32x4_nt *>(dst_al + 16 * kk));
+            }
+        }
+    }
+}
+
 extern "C" uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks) {
     u64 n_tiles = (n_chunks + CP_TILE - 1) / CP_TILE;
     return scl_round_up((n_tiles + 3) * sizeof(u64), 256);  // tile sums, the total, the base of scl_streams_compact_at
@@ -354,10 +499,10 @@ extern "C" uint64_t scl_streams_compact_scratch_bytes(uint64_t n_chunks) {
 // sub-batch i's last offset entry -- which may be the very address it writes its own first entry to (the value is read
 // into the scratch before anything is written).  What lets the compaction of one sub-batch run on a second stream while the
 // next one is still being encoded (backend/models.py encode_dense_pipelined).
-extern "C" int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
-                                      uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
-                                      uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch,
-                                      void *stream) {
+// striped_stride != 0: d_in holds wave-striped slots of that stride (stream c inside logical slot c)
+static int compact_impl(const uint8_t *d_in, u64 striped_stride, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                        uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                        uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch, void *stream) {
     SCL_REQUIRE(mode == SCL_COMPACT_DENSE || mode == SCL_COMPACT_FRAMED, "compact: unknown mode %d", mode);
     SCL_REQUIRE(d_in && d_bit_offset && d_nbits && d_out && d_out_byte_offset && d_scratch,
                 "compact: null pointer argument");
@@ -382,11 +527,37 @@ extern "C" int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit
     hipLaunchKernelGGL(cp_scan_sums, dim3(1), dim3(CP_THREADS), 0, st, tile_sum, n_tiles, total);
     hipLaunchKernelGGL(cp_add_base, dim3((u32)((n_chunks + 1 + 255) / 256)), dim3(256), 0, st, d_out_byte_offset,
                        n_chunks, tile_sum, total, base);
-    const u64 waves_per_block = 256 / SCL_WAVE;
-    hipLaunchKernelGGL(cp_copy, dim3((u32)((n_chunks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, st,
-                       d_in, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset);
+    if (striped_stride) {
+        const u64 spb = 8 * (CPS_THREADS / SCL_WAVE);  // streams per workgroup: eight per wavefront
+        hipLaunchKernelGGL(cp_copy_striped, dim3((u32)((n_chunks + spb - 1) / spb)), dim3(CPS_THREADS), 0, st, d_in,
+                           striped_stride, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset);
+    } else {
+        const u64 waves_per_block = 256 / SCL_WAVE;
+        hipLaunchKernelGGL(cp_copy, dim3((u32)((n_chunks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, st,
+                           d_in, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset);
+    }
     SCL_HIP_TRY(hipGetLastError());
     return SCL_OK;
+}
+
+extern "C" int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,
+                                      uint64_t n_chunks, int mode, uint8_t *d_out, uint64_t out_capacity,
+                                      uint64_t *d_out_byte_offset, const uint64_t *d_base, void *d_scratch,
+                                      void *stream) {
+    return compact_impl(d_in, 0, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset, d_base,
+                        d_scratch, stream);
+}
+
+// (ABI version 8) scl_streams_compact_at for WAVE-STRIPED slots of `in_stride` bytes (what scl_rans_encode_batch_striped /
+// scl_tans_encode_batch_striped write): the same dense / framed records, byte for byte, as the linear form produces.
+extern "C" int scl_streams_compact_striped(const uint8_t *d_in, uint64_t in_stride, const uint64_t *d_bit_offset,
+                                           const uint32_t *d_nbits, uint64_t n_chunks, int mode, uint8_t *d_out,
+                                           uint64_t out_capacity, uint64_t *d_out_byte_offset, const uint64_t *d_base,
+                                           void *d_scratch, void *stream) {
+    SCL_REQUIRE(in_stride % 16 == 0 && in_stride > 0 && in_stride < (1ull << 24) && ((uintptr_t)d_in & 15) == 0,
+                "compact_striped: d_in must be 16-byte aligned and in_stride a multiple of 16 below 2^24");
+    return compact_impl(d_in, in_stride, d_bit_offset, d_nbits, n_chunks, mode, d_out, out_capacity, d_out_byte_offset,
+                        d_base, d_scratch, stream);
 }
 
 extern "C" int scl_streams_compact(const uint8_t *d_in, const uint64_t *d_bit_offset, const uint32_t *d_nbits,

@@ -374,6 +374,85 @@ extern "C" int scl_rans_decode_batch(const scl_rans_model *m, const uint8_t *d_i
 }
 
 // ---- uint16 symbol indices: alphabets up to 65536 (any model; the any-parameter kernels) -------------------
+// ---- wave-striped slots (ABI version 8; scl_ans_fast_io.h: AnsBackWriterT / AnsBitReaderT) -----------------------------
+// The same streams at the same LOGICAL bit positions, the 64 slots of a wave interleaved in 16-byte pieces in memory.
+// Only the tuned kernels have a striped form: a model they do not serve is refused (scl_rans_striped_ok says so up front),
+// and so is a call made while the calling thread keeps the tuned kernels out (scl_set_any_parameter_kernels).
+int rans_striped_encode(const char *what, const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                        u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                        u32 *d_status, hipStream_t st) {
+    SCL_REQUIRE(m->fast && m->dev.K <= 256, "%s: this model is not served by the striped kernels (see scl_*_striped_ok)", what);
+    SCL_REQUIRE(!scl_force_generic(), "%s: the calling thread keeps the tuned kernels out; striped slots have no other", what);
+    SCL_REQUIRE(((uintptr_t)d_out & 15) == 0, "%s: d_out must be 16-byte aligned", what);
+    SCL_REQUIRE(out_stride >= scl_rans_slot_bytes(m, chunk_len) && out_stride < (1ull << 24),
+                "%s: out_stride %llu: striped slots need scl_*_slot_bytes(chunk_len) <= out_stride < 2^24", what,
+                (unsigned long long)out_stride);
+    if (n_chunks == 0) return SCL_OK;
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid
+    if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, st)) return rc_r;
+    if (!scl_rows_aligned(d_sym, sym_stride)) {
+        scl_set_error("%s: out of device memory re-laying unaligned symbol rows (hipMallocAsync failed)", what);
+        return SCL_E_ALLOC;
+    }
+    rans_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits,
+                            d_status, st, true);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+int rans_striped_decode(const char *what, const scl_rans_model *m, const u8 *d_in, u64 in_stride, const u64 *d_bit_off,
+                        const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap, u32 *d_out_lens,
+                        u32 *d_consumed, u32 *d_status, hipStream_t st) {
+    SCL_REQUIRE(m->fast && m->dev.K <= 256, "%s: this model is not served by the striped kernels (see scl_*_striped_ok)", what);
+    SCL_REQUIRE(!scl_force_generic(), "%s: the calling thread keeps the tuned kernels out; striped slots have no other", what);
+    SCL_REQUIRE(((uintptr_t)d_in & 15) == 0 && in_stride % 16 == 0 && in_stride > 0 && in_stride < (1ull << 24),
+                "%s: d_in must be 16-byte aligned and in_stride a multiple of 16 below 2^24", what);
+    if (n_chunks == 0) return SCL_OK;
+    RowRelay relay;  // output rows the kernels cannot store to go through aligned scratch and are copied back
+    if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, st)) return rc_r;
+    if (!scl_rows_aligned(d_out_sym, out_stride)) {
+        scl_set_error("%s: out of device memory re-laying unaligned output rows (hipMallocAsync failed)", what);
+        return SCL_E_ALLOC;
+    }
+    rans_fast_decode_launch(m, d_in, in_stride, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                            d_out_lens, d_consumed, d_status, st, true);
+    SCL_HIP_TRY(hipGetLastError());
+    return relay.out_end(d_out_lens);
+}
+
+extern "C" int scl_rans_striped_ok(const scl_rans_model *m) { return (m && m->fast && m->dev.K <= 256) ? 1 : 0; }
+
+extern "C" int scl_rans_kernel_names_striped(const scl_rans_model *m, uint64_t n_chunks, char *enc, char *dec,
+                                             uint64_t cap) {
+    SCL_REQUIRE(m && (enc || dec) && cap >= 96, "rans_kernel_names_striped: null argument or a buffer below 96 bytes");
+    SCL_REQUIRE(scl_rans_striped_ok(m), "rans_kernel_names_striped: this model is not served by the striped kernels");
+    rans_fast_kernel_names(m, n_chunks, enc, dec, (size_t)cap, true);
+    return SCL_OK;
+}
+
+extern "C" int scl_rans_encode_batch_striped(const scl_rans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                             const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                             uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                             uint32_t *d_out_nbits, uint32_t *d_status, void *stream) {
+    int rc = check_batch_args("rans_encode_batch_striped", m, d_sym, d_out, d_out_bit_offset, d_out_nbits, out_stride);
+    if (rc) return rc;
+    if (int rc_dev = scl_check_device(m->device, "rans_encode_batch_striped")) return rc_dev;
+    return rans_striped_encode("rans_encode_batch_striped", m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out,
+                               out_stride, d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
+}
+
+extern "C" int scl_rans_decode_batch_striped(const scl_rans_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                             const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                             uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                             uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                             uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "rans_decode_batch_striped: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "rans_decode_batch_striped")) return rc_dev;
+    return rans_striped_decode("rans_decode_batch_striped", m, d_in, in_stride, d_bit_offset, d_in_nbits, n_chunks,
+                               d_out_sym, out_stride, out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
+}
+
 extern "C" int scl_rans_encode_batch_u16(const scl_rans_model *m, const uint16_t *d_sym, uint64_t sym_stride,
                                          const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
                                          uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,

@@ -26,6 +26,7 @@
 //
 // Every lane only ever moves whole, aligned 128-byte lines of global memory (input symbols: eight 16-byte loads
 // into registers, next line prefetched); DESIGN.md section 3.1 has the measurements that led there.
+#include <type_traits>
 #include <vector>
 
 #include <stdlib.h>
@@ -55,6 +56,7 @@ __device__ __forceinline__ u32 rf_umulhi(u32 a, u32 b) { return __umulhi(a, b); 
 #define RF_RING_OFF 4096u  // the rings sit behind the 4 KiB symbol table in the workgroup's LDS block
 typedef AnsBackWriterL<RF_THREADS> EncOutL;
 typedef AnsBackWriterS<RF_THREADS> EncOutS;
+typedef AnsBackWriterT<RF_THREADS> EncOutT;  // wave-striped slots, four workgroups per CU (round 6)
 
 // v_mad_u32_u24 d, a, b, c: the compiler splits __umul24(a, b) + (c1 + c2) into v_mul_u32_u24 + v_add3_u32 (two
 // half-rate instructions); one full-rate add feeding the multiply-add is cheaper
@@ -186,7 +188,9 @@ __device__ __forceinline__ void rf_encode16(const uint4 v, u32 next_w, Entries4 
 }
 
 template <typename EncOut, int CHECK_SYM, int MSH_T, int R_T, int NB_T = 1>
-__global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
+// (alphabets below 256 symbols carry the SWAR symbol check: a few registers more than the 128 that four workgroups per CU
+// leave -- the striped writer then runs three)
+__global__ void __launch_bounds__(RF_THREADS, (EncOut::STRIPED && CHECK_SYM) ? 3 : EncOut::WG_PER_CU) rans_encode_fast_kernel(RansFastDev P, const u8 *__restrict__ sym,
                                                                         u64 sym_stride,
                                                                         const u32 *__restrict__ lens, u32 chunk_len,
                                                                         u64 n_chunks, u8 *__restrict__ out,
@@ -210,15 +214,22 @@ __global__ void __launch_bounds__(RF_THREADS, EncOut::WG_PER_CU) rans_encode_fas
     // is then a uniform base + one 32-bit register, which is also all a helper lane needs to know of its source
     u8 *wg_out = out + (u64)blockIdx.x * RF_THREADS * out_stride;
     EncOut o;
-    o.init(threadIdx.x, (threadIdx.x + 1) * (u32)out_stride);
+    if constexpr (EncOut::STRIPED)
+        o.init(threadIdx.x, (u32)out_stride);  // the 64 slots of a wave interleaved in 16-byte pieces (AnsBackWriterT)
+    else
+        o.init(threadIdx.x, (threadIdx.x + 1) * (u32)out_stride);
     // whole wave, equally long chunks: every lane reaches every flush point, so the quads can store cooperatively
     const bool coop_out = __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
-#define RF_FLUSH()                                 \
-    do {                                           \
-        if (coop_out)                              \
-            o.flush_quad(lds, wg_out, threadIdx.x); \
-        else                                       \
-            o.flush_lane(lds, wg_out);             \
+#define RF_FLUSH()                                   \
+    do {                                             \
+        if constexpr (EncOut::STRIPED) {             \
+            o.flush(lds, wg_out, NB_T == 1 ? 72u : 60u); \
+        } else {                                     \
+            if (coop_out)                            \
+                o.flush_quad(lds, wg_out, threadIdx.x); \
+            else                                     \
+                o.flush_lane(lds, wg_out);           \
+        }                                            \
     } while (0)
     u32 x = P.L;
     u32 bad = 0;
@@ -429,7 +440,9 @@ __device__ __forceinline__ uint4 rf_decode16(u32 &x, DecIn &r, char *lds, const 
     return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-template <int ML_T, int CB_T, int THREADS, int NB_T = 1>
+// STRIPED: the input is in wave-striped slots (AnsBackWriterT / AnsBitReaderT, scl_ans_fast_io.h); `in_size_bytes` then
+// carries the slot stride and stream c lies in slot c.
+template <int ML_T, int CB_T, int THREADS, int NB_T = 1, bool STRIPED = false>
 __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P, const u8 *__restrict__ in,
                                                                      u64 in_size_bytes,
                                                                      const u64 *__restrict__ bit_off,
@@ -440,7 +453,7 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
                                                                      u32 *__restrict__ status) {
     // slot table first: its offsets (< 32 KiB) then need no base added (a DS offset field reaches 64 KiB); the ring
     // works on addresses relative to its own base, which the DS offset field supplies
-    typedef AnsBitReaderW<THREADS> DecIn;
+    typedef typename std::conditional<STRIPED, AnsBitReaderT<THREADS>, AnsBitReaderW<THREADS>>::type DecIn;
     __shared__ __attribute__((aligned(16))) char s_lds[4096 * 8 + DecIn::RING_BYTES];
     char *lds = s_lds + 4096 * 8;
     const char *tab = s_lds;
@@ -462,7 +475,10 @@ __global__ void __launch_bounds__(THREADS) rans_decode_fast_kernel(RansFastDev P
         return;
     }
     DecIn r;
-    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
+    if constexpr (STRIPED)
+        r.init(in, in_size_bytes, c, bit_off[c], lds, threadIdx.x);
+    else
+        r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, P.size_bits);
     u32 x = r.get(lds, P.nsb);
     x <<= XSH;
@@ -704,14 +720,16 @@ bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks) {
 // mechanically against profiles/*_kernel_trace_summary.txt).
 struct RfEncChoice {
     bool slots;  // AnsBackWriterS (three workgroups per CU) instead of AnsBackWriterL
+    bool striped;  // AnsBackWriterT: wave-striped slots (four workgroups per CU)
     int check;   // CHECK_SYM: 0 = 256 symbols, 1 = K <= 128, 2 = 129..255
     int msh;     // MSH_T: 10 = the literal (MSH, r) = (10, 16) form, -1 = pre-shift folded into the reciprocals, 0 = run time
     int r;       // R_T (16 with msh = 10, else 0)
     int nb;      // NB_T: 1 = NUM_BITS_OUT 1, 0 = NUM_BITS_OUT in {4, 8, 16}
 };
-static RfEncChoice rf_encode_choice(const scl_rans_model *m, u64 n_chunks) {
+static RfEncChoice rf_encode_choice(const scl_rans_model *m, u64 n_chunks, bool striped) {
     RfEncChoice c;
-    c.slots = rf_use_slot_writer(m, n_chunks);
+    c.slots = !striped && rf_use_slot_writer(m, n_chunks);
+    c.striped = striped;
     c.check = m->fdev.K == 256 ? 0 : (m->fdev.K <= 128 ? 1 : 2);
     if (m->fdev.b != 1) {  // NUM_BITS_OUT in {4, 8, 16}: run-time constants
         c.msh = 0, c.r = 0, c.nb = 0;
@@ -727,15 +745,17 @@ static RfEncChoice rf_encode_choice(const scl_rans_model *m, u64 n_chunks) {
 
 void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
-                             u32 *d_status, hipStream_t st) {
+                             u32 *d_status, hipStream_t st, bool striped) {
     const u32 blocks = (u32)((n_chunks + RF_THREADS - 1) / RF_THREADS);
-    const RfEncChoice ch = rf_encode_choice(m, n_chunks);
+    const RfEncChoice ch = rf_encode_choice(m, n_chunks, striped);
 #define RF_LAUNCH_ENC_K(OUT, CHECK, MSH, R, NB)                                                                       \
     hipLaunchKernelGGL((rans_encode_fast_kernel<OUT, CHECK, MSH, R, NB>), dim3(blocks), dim3(RF_THREADS), 0, st, m->fdev, \
                        d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
 #define RF_LAUNCH_ENC_W(CHECK, MSH, R, NB)                  \
     do {                                                    \
-        if (ch.slots)                                       \
+        if (ch.striped)                                     \
+            RF_LAUNCH_ENC_K(EncOutT, CHECK, MSH, R, NB);    \
+        else if (ch.slots)                                  \
             RF_LAUNCH_ENC_K(EncOutS, CHECK, MSH, R, NB);    \
         else                                                \
             RF_LAUNCH_ENC_K(EncOutL, CHECK, MSH, R, NB);    \
@@ -784,29 +804,38 @@ static RfDecChoice rf_decode_choice(const scl_rans_model *m, u64 n_chunks) {
 }
 
 // the two kernels of a batch of n_chunks aligned, equally long rows, as rocprofv3 prints them
-void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap) {
-    const RfEncChoice e = rf_encode_choice(m, n_chunks);
+void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap, bool striped) {
+    const RfEncChoice e = rf_encode_choice(m, n_chunks, striped);
     const RfDecChoice d = rf_decode_choice(m, n_chunks);
     if (enc)
-        snprintf(enc, cap, "rans_encode_fast_kernel<AnsBackWriter%c<256>, %d, %d, %d, %d>", e.slots ? 'S' : 'L', e.check, e.msh,
+        snprintf(enc, cap, "rans_encode_fast_kernel<AnsBackWriter%c<256>, %d, %d, %d, %d>", e.striped ? 'T' : (e.slots ? 'S' : 'L'), e.check, e.msh,
                  e.r, e.nb);
-    if (dec) snprintf(dec, cap, "rans_decode_fast_kernel<%d, %d, %d, %d>", d.ml, d.cb, d.threads, d.nb);
+    if (dec)
+        snprintf(dec, cap, striped ? "rans_decode_fast_kernel<%d, %d, %d, %d, true>" : "rans_decode_fast_kernel<%d, %d, %d, %d>",
+                 d.ml, d.cb, d.threads, d.nb);
 }
 
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
-                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
+                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st, bool striped) {
     const RfDecChoice ch = rf_decode_choice(m, n_chunks);
-#define RF_LAUNCH_DEC_K(ML, CB, TH, NB)                                                                               \
-    hipLaunchKernelGGL((rans_decode_fast_kernel<ML, CB, TH, NB>), dim3((u32)((n_chunks + TH - 1) / TH)), dim3(TH), 0, st, \
-                       m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,   \
+#define RF_LAUNCH_DEC_K(ML, CB, TH, NB, ST)                                                                           \
+    hipLaunchKernelGGL((rans_decode_fast_kernel<ML, CB, TH, NB, ST>), dim3((u32)((n_chunks + TH - 1) / TH)), dim3(TH), 0, \
+                       st, m->fdev, d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, \
                        d_out_lens, d_consumed, d_status)
+#define RF_LAUNCH_DEC_T(ML, CB, TH, NB)                     \
+    do {                                                    \
+        if (striped)                                        \
+            RF_LAUNCH_DEC_K(ML, CB, TH, NB, true);          \
+        else                                                \
+            RF_LAUNCH_DEC_K(ML, CB, TH, NB, false);         \
+    } while (0)
 #define RF_LAUNCH_DEC(ML, CB, NB)                           \
     do {                                                    \
         if (ch.threads == RD_THREADS)                       \
-            RF_LAUNCH_DEC_K(ML, CB, RD_THREADS, NB);        \
+            RF_LAUNCH_DEC_T(ML, CB, RD_THREADS, NB);        \
         else                                                \
-            RF_LAUNCH_DEC_K(ML, CB, RD_THREADS_SMALL, NB);  \
+            RF_LAUNCH_DEC_T(ML, CB, RD_THREADS_SMALL, NB);  \
     } while (0)
     if (ch.nb == 0)
         RF_LAUNCH_DEC(0, 0, 0);
@@ -819,5 +848,6 @@ void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_siz
     else
         RF_LAUNCH_DEC(0, 0, 1);
 #undef RF_LAUNCH_DEC
+#undef RF_LAUNCH_DEC_T
 #undef RF_LAUNCH_DEC_K
 }

@@ -71,13 +71,23 @@ struct scl_rans_model {
 // scl_rans_fast.hip
 int rans_fast_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum);
 bool rf_use_slot_writer(const scl_rans_model *m, u64 n_chunks);
-void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap);
+// striped: wave-striped slots (AnsBackWriterT / AnsBitReaderT, scl_ans_fast_io.h) -- d_out holds round_up(n_chunks, 64)
+// slots; the decoder's `in_size_bytes` is then the slot stride
+void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, char *dec, size_t cap, bool striped = false);
 void rans_fast_encode_launch(const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                              u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
-                             u32 *d_status, hipStream_t st);
+                             u32 *d_status, hipStream_t st, bool striped = false);
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                              const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
-                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);
+                             u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st, bool striped = false);
+
+// scl_rans.hip: the striped entry points' bodies (shared with the tANS models the table-free rANS kernels serve)
+int rans_striped_encode(const char *what, const scl_rans_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
+                        u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
+                        u32 *d_status, hipStream_t st);
+int rans_striped_decode(const char *what, const scl_rans_model *m, const u8 *d_in, u64 in_stride, const u64 *d_bit_off,
+                        const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap, u32 *d_out_lens,
+                        u32 *d_consumed, u32 *d_status, hipStream_t st);
 
 // scl_rans_fast_b.hip (NUM_BITS_OUT > 1)
 int rans_fastb_build_tables(scl_rans_model *m, const u32 *h_freq, const u32 *h_cum);

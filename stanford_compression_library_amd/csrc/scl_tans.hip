@@ -384,6 +384,45 @@ extern "C" int scl_tans_kernel_names(const scl_tans_model *m, uint64_t n_chunks,
     return SCL_OK;
 }
 
+// ---- wave-striped slots (ABI version 8): tANS models the table-free rANS kernels serve, on their striped form ----------
+extern "C" int scl_tans_striped_ok(const scl_tans_model *m) {
+    return (m && m->rans && m->rans->fast && m->dev.K <= 256) ? 1 : 0;
+}
+
+extern "C" int scl_tans_kernel_names_striped(const scl_tans_model *m, uint64_t n_chunks, char *enc, char *dec,
+                                             uint64_t cap) {
+    SCL_REQUIRE(m && (enc || dec) && cap >= 96, "tans_kernel_names_striped: null argument or a buffer below 96 bytes");
+    SCL_REQUIRE(scl_tans_striped_ok(m), "tans_kernel_names_striped: this model is not served by the striped kernels");
+    rans_fast_kernel_names(m->rans, n_chunks, enc, dec, (size_t)cap, true);
+    return SCL_OK;
+}
+
+extern "C" int scl_tans_encode_batch_striped(const scl_tans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                             const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                             uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                             uint32_t *d_out_nbits, uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "tans_encode_batch_striped: null pointer argument");
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0, "tans_encode_batch_striped: bad out_stride %llu",
+                (unsigned long long)out_stride);
+    if (int rc_dev = scl_check_device(m->device, "tans_encode_batch_striped")) return rc_dev;
+    SCL_REQUIRE(scl_tans_striped_ok(m), "tans_encode_batch_striped: this model is not served by the striped kernels");
+    return rans_striped_encode("tans_encode_batch_striped", m->rans, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out,
+                               out_stride, d_out_bit_offset, d_out_nbits, d_status, (hipStream_t)stream);
+}
+
+extern "C" int scl_tans_decode_batch_striped(const scl_tans_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                             const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                             uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                             uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                             uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "tans_decode_batch_striped: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "tans_decode_batch_striped")) return rc_dev;
+    SCL_REQUIRE(scl_tans_striped_ok(m), "tans_decode_batch_striped: this model is not served by the striped kernels");
+    return rans_striped_decode("tans_decode_batch_striped", m->rans, d_in, in_stride, d_bit_offset, d_in_nbits, n_chunks,
+                               d_out_sym, out_stride, out_cap, d_out_lens, d_consumed, d_status, (hipStream_t)stream);
+}
+
 extern "C" int scl_tans_encode_batch(const scl_tans_model *m, const uint8_t *d_sym, uint64_t sym_stride,
                                      const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks, uint8_t *d_out,
                                      uint64_t out_stride, uint64_t *d_out_bit_offset, uint32_t *d_out_nbits,

@@ -49,7 +49,7 @@ def test_binding_matches_header(built_lib):
 
 def test_abi_version_and_error_string(built_lib):
     built_lib.scl_abi_version.restype = ctypes.c_int
-    assert built_lib.scl_abi_version() == 7
+    assert built_lib.scl_abi_version() == 8
     built_lib.scl_last_error.restype = ctypes.c_char_p
     assert isinstance(built_lib.scl_last_error(), bytes)
 
