@@ -472,9 +472,7 @@ struct AnsBackWriterS {
 //   * bit window, check(): as AnsBackWriterL (the asm block differs in the ring constants only);
 //   * ring: 32 words per lane, [thread][word], words in MEMORY order inside 16-byte pieces, rotated by 16 * (lane mod 8)
 //     bytes against lockstep tables; flush points 32 symbols apart (<= 13 new words on top of <= 3 pending + 16 to spare);
-//   * flush(): rounds -- in each round every lane that holds a complete piece reads it (one ds_read_b128) and stores it at
-//     its own row (the lanes of a wave are within a row or two of each other: the 64 pieces of a round fall into two or
-//     three rows, contiguous where neighbours agree).
+//   * flush(): the wave stores the next row when every lane holds a complete piece (see the comment there).
 __device__ __forceinline__ u64 scl_stripe_byte(u64 logical_byte, u64 stride) {
     // logical byte address in a batch of slots of `stride` bytes (a multiple of 16) -> physical byte address
     const u64 slot = logical_byte / stride, b = logical_byte - slot * stride;
@@ -495,8 +493,6 @@ struct AnsBackWriterT {
     u32 base;     // tid * LANE_BYTES
     u32 goff;     // byte offset (from the workgroup's output base) of this lane's next piece
     u32 goff0;    // ... of its first piece (the last 16 bytes of its logical slot)
-    u32 np;       // pieces this lane has stored
-    u32 rs;       // rows the whole wave has stored (the same value in every lane; np >= rs)
 
     __device__ __forceinline__ u32 pend4() const { return (th4 - wa) & 127u; }  // 4 * completed words not yet stored
 
@@ -508,7 +504,6 @@ struct AnsBackWriterT {
         th4 = (124u + 16u * (tid & 7u)) & 127u;
         wa = base | th4;
         goff = goff0 = ((tid >> 6) + 1u) * (out_stride << 6) - 1024u + ((tid & 63u) << 4);
-        np = rs = 0;
     }
     __device__ __forceinline__ void push(u32 v, u32 k) {  // the low k bits of v go in front of the stream; k < 32
         lo = __builtin_amdgcn_alignbit(hi, lo, k);
@@ -548,36 +543,61 @@ struct AnsBackWriterT {
             check<RING_OFF>(lds, w);
         }
     }
-    __device__ __forceinline__ void store_piece(char *lds, u8 *wg_out) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(lds + base + ((th4 - 12u) & 127u));
-        {
-            typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
-            const u32x4_nt t = {q.x, q.y, q.z, q.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(wg_out + goff));
-        }
-        goff -= 1024u;
-        th4 = (th4 - 16u) & 127u;
-        np += 1u;
+    // piece r (0 = oldest) of the complete ones this lane holds -> its row; nothing is updated (see rows_done)
+    template <u32 R>
+    __device__ __forceinline__ void store_row(char *lds, u8 *wg_out) const {
+        const uint4 q = *reinterpret_cast<const uint4 *>(lds + base + ((th4 - 12u - 16u * R) & 127u));
+        typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
+        const u32x4_nt t = {q.x, q.y, q.z, q.w};
+        // non-temporal: a row is written once, whole, and read next by another kernel (same-box alternation: the round trip
+        // is 1 % faster with the hint; AnsBackWriterL's quad stores were neutral with it)
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(wg_out + goff - 1024u * R));
+    }
+    __device__ __forceinline__ void rows_done(u32 m) {
+        goff -= 1024u * m;
+        th4 = (th4 - 16u * m) & 127u;
     }
     // Flush point (any subset of the wave may call; the lanes present act together).  Lanes complete their pieces at
     // data-dependent times; a piece stored the moment it is complete makes every 128-byte line arrive in two or three
-    // partial writes (measured: +0.13 ms per GiB batch, worse than the L writer).  So the wave stores ROW BY ROW: row rs goes
-    // out when every lane present has it complete (or has already stored it) -- one instruction, 64 adjacent pieces, eight
-    // whole lines -- and the ring absorbs the lanes' drift (a lane may hold up to GUARD bytes of complete words when it
-    // leaves; beyond that it stores its own oldest pieces, partial lines, rare -- the ring must never hold 32 words).
+    // partial writes (measured: +0.13 ms per GiB batch, worse than the L writer).  So the wave stores ROW BY ROW: the next
+    // row goes out when EVERY lane present holds a complete piece -- one instruction, 64 adjacent pieces, eight whole lines
+    // when the lanes are where i.i.d. data keeps them: in step to within a piece or two, which the ring absorbs (a lane may
+    // leave a flush point holding up to `guard` bytes of complete words).  A lane beyond that stores its own oldest pieces
+    // -- partial lines; lanes that drift apart for good (very different statistics from chunk to chunk) all end up there,
+    // at the cost of the unsynchronised form (+3 %), never of correctness: the ring cannot reach 32 words.
     // guard: 4 * (31 - the most words 32 symbols can complete): 72 for <= 13 bits per symbol, 60 for <= 16
     __device__ __forceinline__ void flush(char *lds, u8 *wg_out, u32 guard) {
-        for (;;) {
-            const bool has = pend4() >= 16u;
-            const bool ready = has || np > rs;
-            if (__builtin_amdgcn_ballot_w64(ready) != __builtin_amdgcn_ballot_w64(true)) break;
-            if (np == rs) store_piece(lds, wg_out);
-            rs += 1u;
+        const u32 p = pend4();
+        const u64 all = __builtin_amdgcn_ballot_w64(true);
+        if (__builtin_amdgcn_ballot_w64(p >= 16u) == all) {
+            store_row<0>(lds, wg_out);
+            if (__builtin_amdgcn_ballot_w64(p >= 32u) == all) {
+                store_row<1>(lds, wg_out);
+                if (__builtin_amdgcn_ballot_w64(p >= 48u) == all) {
+                    store_row<2>(lds, wg_out);
+                    if (__builtin_amdgcn_ballot_w64(p >= 64u) == all) {
+                        store_row<3>(lds, wg_out);
+                        rows_done(4);
+                    } else {
+                        rows_done(3);
+                    }
+                } else {
+                    rows_done(2);
+                }
+            } else {
+                rows_done(1);
+            }
         }
-        while (pend4() > guard) store_piece(lds, wg_out);
+        while (pend4() > guard) {
+            store_row<0>(lds, wg_out);
+            rows_done(1);
+        }
     }
     __device__ __forceinline__ void flush_all(char *lds, u8 *wg_out) {  // per lane
-        while (pend4() >= 16u) store_piece(lds, wg_out);
+        while (pend4() >= 16u) {
+            store_row<0>(lds, wg_out);
+            rows_done(1);
+        }
     }
     __device__ __forceinline__ u64 finish(char *lds, u8 *wg_out) {  // per lane; returns the stream length in bits
         flush_all(lds, wg_out);
@@ -591,7 +611,7 @@ struct AnsBackWriterT {
         const u32 n = 32u - room;  // <= 32 after the last check(): the top n bits of hi, zero bits in front of them
         // (nw <= 3; with n != 0 and nw == 3 the word lands at piece + 0)
         if (n) *reinterpret_cast<u32 *>(piece + 12u - 4u * nw) = __builtin_bswap32(n == 32 ? hi : (hi >> (32 - n)));
-        return (u64)(np * 4u + nw) * 32 + n;
+        return (u64)(((goff0 - goff) >> 10) * 4u + nw) * 32 + n;
     }
 };
 
