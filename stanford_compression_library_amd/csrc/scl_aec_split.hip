@@ -43,10 +43,10 @@
 #define AS_PLANE (AS_LANES * 4)        // one u32 of every chunk
 #define AS_ROW_BYTES (8 * AS_PLANE)    // 8 KiB per context
 #define AS_TABLE_BYTES (16 * AS_ROW_BYTES)
-#define AS_TOT_BASE AS_TABLE_BYTES     // u16 totals [ctx][lane]
-#define AS_TOT_ROW (AS_LANES * 2)
-#define AS_TOT_BYTES (16 * AS_TOT_ROW)
-#define AS_LUT_BASE (AS_TOT_BASE + AS_TOT_BYTES)
+// The row TOTAL lives in the row itself (round 6): X[0], the exclusive cumulative count of symbol 0, is always 0, so its
+// u16 carries the total instead -- the addend rows count it up with every symbol (one LDS atomic per symbol less than the
+// separate totals array of rounds 3-5 took), the lookup masks it out for s = 0.
+#define AS_LUT_BASE AS_TABLE_BYTES
 #define AS_LUT_BYTES 512
 #define AS_TILE 4                      // symbols per lane and barrier: 2 or 4 (a 32-bit word of symbols is 4 / AS_TILE tiles)
 #define AS_RPW (4 / AS_TILE)            // rounds per word of symbols
@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(AS_THREADS)
     // ---- tables, LUT, the longest chunk of the workgroup ----------------------------------------------------------
     if (tid < 128) {
         const u32 s = tid >> 3, r = tid & 7;  // addend of word r (counts 2r, 2r + 1) for symbol s: [j > s]
-        const u32 v = ((2 * r > s) ? 1u : 0u) | ((2 * r + 1 > s) ? 0x10000u : 0u);
+        // (count 0 of a row is its total: + 1 for every symbol)
+        const u32 v = ((2 * r > s || r == 0) ? 1u : 0u) | ((2 * r + 1 > s) ? 0x10000u : 0u);
         *reinterpret_cast<u32_lds *>(lds + AS_LUT_BASE + s * 32 + r * 4) = v;
     }
     if (tid == 0) *reinterpret_cast<u32_lds *>(lds + AS_RED_BASE) = 0;
@@ -105,8 +106,8 @@ __global__ void __launch_bounds__(AS_THREADS)
         for (u32 c = 0; c < P.nctx; ++c) {
 #pragma unroll
             for (u32 w = 0; w < 8; ++w)
-                *reinterpret_cast<u32_lds *>(lds + c * AS_ROW_BYTES + w * AS_PLANE + lane * 4) = P.initX[w];
-            *reinterpret_cast<u16_lds *>(lds + AS_TOT_BASE + c * AS_TOT_ROW + lane * 2) = (u16)P.total0;
+                *reinterpret_cast<u32_lds *>(lds + c * AS_ROW_BYTES + w * AS_PLANE + lane * 4) =
+                    w ? P.initX[w] : ((P.initX[0] & 0xFFFF0000u) | (P.total0 & 0xFFFFu));
         }
     }
     __syncthreads();
@@ -128,9 +129,7 @@ __global__ void __launch_bounds__(AS_THREADS)
         u32 st = 0;
         u32 ctx = 0;
         u32 nextw = src[0];
-        const u32 tot_inc = 1u << (16 * (lane & 1));
         const u32 lane4 = lane * 4;
-        u32 *tot32 = reinterpret_cast<u32 *>(lds + AS_TOT_BASE) + (lane >> 1);
         for (u32 w = 0; w < n_words; ++w) {
             const u32 word = nextw;
             nextw = src[min(w + 1, last_word)];  // one word ahead, never conditional
@@ -158,7 +157,7 @@ __global__ void __launch_bounds__(AS_THREADS)
                     const u32 wa = rowaddr + (s[q] >> 1) * AS_PLANE;
                     w0[j] = *reinterpret_cast<const u32_lds *>(lds + wa);
                     w1[j] = *reinterpret_cast<const u32_lds *>(lds + wa + AS_PLANE);
-                    T[j] = *reinterpret_cast<const u16_lds *>(lds + AS_TOT_BASE + ctx * AS_TOT_ROW + lane * 2);
+                    T[j] = *reinterpret_cast<const u16_lds *>(lds + rowaddr);  // count 0 of the row = its total
                     // update_model: X[j] += 1 for j > s, total += 1 -- no register round trip
                     {
                         u32 *row = reinterpret_cast<u32 *>(lds + rowaddr);
@@ -167,8 +166,6 @@ __global__ void __launch_bounds__(AS_THREADS)
                         for (u32 p = 0; p < 8; ++p)
                             __hip_atomic_fetch_add(row + p * (AS_PLANE / 4), add[p], __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(tot32 + ctx * (AS_TOT_ROW / 4), tot_inc, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     ctx = as_next_ctx<ORDER1>(P, ctx, s[q]);
                 }
@@ -176,6 +173,7 @@ __global__ void __launch_bounds__(AS_THREADS)
                 for (u32 j = 0; j < AS_TILE; ++j) {
                     const u32 q = AS_TILE * half + j;
                     u32 cd = __builtin_amdgcn_alignbit(w1[j], w0[j], 16 * (s[q] & 1));
+                    if (s[q] == 0) cd &= 0xFFFF0000u;                   // X[0] = 0 (its cell holds the total)
                     if (s[q] == 15) cd = (cd & 0xFFFFu) | (T[j] << 16);  // X[16] is the total
                     const double x = af_recip((double)T[j]);
                     *reinterpret_cast<double *>(lds + AS_F1X_BASE + (buf * AS_TILE + j) * AS_F1X_SLOT + lane * 8) = x;
@@ -278,6 +276,10 @@ __global__ void __launch_bounds__(AS_THREADS)
     // 64-bit window hi:lo, `cnt` pending bits bottom-aligned (cnt < 32 between symbols); a field is at most 31 bits, so
     // the window never holds more than 62.  32-bit shifts only (see AnsFwdWriter::put, scl_ans_fast_io.h).  A completed
     // big-endian word goes straight to the slot (4-byte stores; the stream is a third of the input and L2 merges them).
+    // Round 6 staged the words in LDS (the 2 KiB the totals vacated) and stored whole 32-byte sectors: the same streams,
+    // but the writer role -- one of three that pace each other -- grew by a tenth and the kernel went from 4.7 to 5.05 ms
+    // (5.4 with the sector's store deferred by a round): not kept.  The 3 x HBM traffic of these word stores (sectors
+    // written back partly filled) is 0.94 TB/s and bounds nothing here.
     u32 *dst = reinterpret_cast<u32 *>(out + (live ? chunk : 0) * out_stride);
     u32 whi = 0, wlo = 0, cnt = 0, nwords = 0;
     auto push = [&](u32 v, u32 nb) {  // v < 2^nb, nb <= 31; nb = 0 pushes nothing

@@ -670,6 +670,22 @@ def test_tuned_kernels_full_occupancy_stress(mode, dev):
         assert model.fast_path(chunk_len)
     ref = model.encode_batch(sym, any_parameter_kernels=True)
     torch.cuda.synchronize()
+    # ... and the any-parameter kernels' own streams against the ORACLE on a sample of the distinct-data batch (VERDICT r5
+    # weak #11: word-for-word agreement of two GPU implementations alone would not notice a shared misreading)
+    sample = [0, 1, 63, 64, 255, 256, 4095, n_chunks // 2, n_chunks - 2, n_chunks - 1]
+    o_enc = {"fixed": lambda s_: orc.aec_encode(s_, orc.MODEL_FIXED, 256, f_init=freq),
+             "iid": lambda s_: orc.aec_encode(s_, orc.MODEL_IID, 256, f_init=np.ones(256)),
+             "order1": lambda s_: orc.aec_encode(s_, orc.MODEL_ORDERK, 16, k=1),
+             "rans": lambda s_: orc.rans_encode(s_, freq), "rans_total_3000": lambda s_: orc.rans_encode(s_, freq),
+             "tans": lambda s_: orc.tans_encode(s_, freq, RF=1), "range": lambda s_: orc.range_encode(s_, freq)}[mode]
+    host_rows = sym[sample].cpu().numpy()
+    s_off, s_nb = ref.bit_offset[sample].cpu().numpy(), ref.nbits[sample].cpu().numpy()
+    for j, c in enumerate(sample):
+        rb, rn = o_enc(host_rows[j])
+        assert int(s_nb[j]) == rn, f"{mode} chunk {c}: {s_nb[j]} bits vs oracle {rn}"
+        lo = int(s_off[j]) // 8
+        piece = ref.data[lo:lo + (int(s_off[j]) % 8 + rn + 7) // 8 + 1].cpu().numpy()
+        assert np.array_equal(_stream_bits(piece, int(s_off[j]) % 8, rn), np.unpackbits(rb)[:rn]), f"{mode} chunk {c} vs oracle"
     stride = ref.stride
     nwords = int((ref.nbits.max().item() + 31) // 32)
     back = mode in ("rans", "tans", "rans_total_3000")  # ANS streams end at the slot end, the others start at its front
