@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -161,6 +162,15 @@ def load(path: str = None) -> C.CDLL:
         if not os.path.exists(p):
             raise SclHipError(E_NODEVICE, "load", f"{p} not found: build it with __graft_entry__.build() "
                               "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        if "torch" not in sys.modules:
+            # One HIP runtime per process: torch bundles its own libamdhip64, libscl_hip.so resolves to the system's.  Whichever
+            # is loaded first serves both -- but if the system's comes first, torch later initialises ITS copy beside it and
+            # finds no devices ("No HIP GPUs are available": __graft_entry__.build() followed by smoke() in one process,
+            # round 6).  The batch entry points are fed by torch tensors anyway: let torch's runtime be the first.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(p)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI and the binding disagree
