@@ -299,7 +299,7 @@ int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, co
  * so that piece q of the 64 lanes of a wave is one contiguous kilobyte.  A lane then stores 16 bytes at a time where the
  * linear layout made it buffer whole 128-byte lines (256 B of LDS per lane: two waves per SIMD); the striped encoder runs
  * four waves per SIMD and stores row by row, 64 adjacent pieces per instruction.  d_out must hold
- * round_up(n_chunks, 64) * out_stride bytes.  Worth it for batches that fill the chip (>= ~131 072 chunks on MI355X:
+ * round_up(n_chunks, 64) * out_stride bytes.  Worth it for batches that fill the chip (>= ~196 608 chunks on MI355X:
  * 1 GiB headline batch encode 0.55 -> 0.52 ms); smaller batches are faster on the linear entry points.
  *   scl_*_striped_ok              1 if the striped entry points serve this model (= the tuned kernels do: fast_path with
  *                                 NUM_BITS_OUT = 1 or in {4, 8, 16}, alphabet <= 256), else 0 -- they then fail with

@@ -74,7 +74,10 @@ class EncodedBatch:
         return torch.cat([body, self.data.new_zeros(16)])
 
 
-STRIPED_MIN_CHUNKS = 131072  # layout="auto": batches from this size on take the striped kernels (they need the chip full)
+# layout="auto": batches from this size on take the striped kernels.  They win by occupancy (four 256-lane workgroups per CU
+# against two), so they need the chip full: measured on MI355X (256 CUs) 65 536 chunks -17 %, 131 072 chunks -6 % (two
+# workgroups per CU either way), 196 608 chunks +2.7 %, 262 144 chunks +3.5 % on the round trip (profiles/r06_striped_ab.txt)
+STRIPED_MIN_CHUNKS = 196608
 
 
 class _DeviceModel:

@@ -811,8 +811,8 @@ void rans_fast_kernel_names(const scl_rans_model *m, u64 n_chunks, char *enc, ch
         snprintf(enc, cap, "rans_encode_fast_kernel<AnsBackWriter%c<256>, %d, %d, %d, %d>", e.striped ? 'T' : (e.slots ? 'S' : 'L'), e.check, e.msh,
                  e.r, e.nb);
     if (dec)
-        snprintf(dec, cap, striped ? "rans_decode_fast_kernel<%d, %d, %d, %d, true>" : "rans_decode_fast_kernel<%d, %d, %d, %d>",
-                 d.ml, d.cb, d.threads, d.nb);
+        snprintf(dec, cap, "rans_decode_fast_kernel<%d, %d, %d, %d, %s>", d.ml, d.cb, d.threads, d.nb,
+                 striped ? "true" : "false");
 }
 
 void rans_fast_decode_launch(const scl_rans_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,

@@ -18,7 +18,7 @@ import pytest
 from conftest import ROOT
 
 PROF = os.path.join(ROOT, "profiles")
-ROUND = "r05"
+ROUND = "r06"
 
 
 def _line(path):

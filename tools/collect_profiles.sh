@@ -1,6 +1,6 @@
 #!/bin/bash
 # collect_profiles.sh: gpurun_out/prof_<name>/ and gpurun_out/$R/ -> profiles/$R_* (the files the docs cite); R=r04 by default
-R=${R:-r05}
+R=${R:-r06}
 cd "$(dirname "$0")/.."
 for d in gpurun_out/prof_*/; do
   n=$(basename $d); n=${n#prof_}
