@@ -724,7 +724,8 @@ def rooflines(res):
         # priced at the same algorithmic bytes (symbols read + stream bytes written once).  `sequential_ms` = the two one
         # after the other; `pipelined_ms` = the same result in two sub-batches on two streams (DensePipeline), the whole
         # operation timed; `frac` is on the faster of the two
-        r_dense = {"bound": "hbm", "kernels": [k_enc, "cp_scan_tiles + cp_scan_sums + cp_add_base + cp_copy"],
+        cp = "cp_copy_striped" if res.get("layout") == "striped" else "cp_copy"
+        r_dense = {"bound": "hbm", "kernels": [k_enc, "cp_scan_tiles + cp_scan_sums + cp_add_base + " + cp],
                    "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                    "algorithmic_bytes_per_launch": alg, "encode_ms": round(res["enc_ms"], 4),
                    "compact_ms": round(res["compact_ms"], 4), "sequential_ms": round(seq_ms, 4),
