@@ -45,14 +45,20 @@ def _families():
     odd_total = np.array([3, 1, 7, 2, 19, 40, 5, 9], dtype=np.int64)  # total 86: the exact-division rANS decoder
     wide = np.random.default_rng(5).integers(1, 20, 700).astype(np.int64)
 
-    def f(make, K, freq, env=None, any_par=False, u16=False):
-        return dict(make=make, K=K, freq=freq, env=env or {}, any_par=any_par, u16=u16)
+    def f(make, K, freq, env=None, any_par=False, u16=False, striped=False):
+        return dict(make=make, K=K, freq=freq, env=env or {}, any_par=any_par, u16=u16, striped=striped)
 
     return {
         "rans_b1": f(lambda: models.RansModel(t256.tolist(), 1 << 16, 1, 32), 256, t256),
         "rans_b1_total86": f(lambda: models.RansModel(odd_total.tolist(), 1 << 16, 1, 32), 8, odd_total),
         "rans_b8": f(lambda: models.RansModel(t256.tolist(), 1 << 8, 8, 32), 256, t256),
         "rans_any": f(lambda: models.RansModel(t256.tolist(), 1 << 16, 1, 32), 256, t256, any_par=True),
+        # wave-striped slots (ABI 8): the same decoders behind AnsBitReaderT -- piece-granular refill, per-lane row offsets
+        # clamped to the lane's slot
+        "rans_b1_striped": f(lambda: models.RansModel(t256.tolist(), 1 << 16, 1, 32), 256, t256, striped=True),
+        "rans_b1_total86_striped": f(lambda: models.RansModel(odd_total.tolist(), 1 << 16, 1, 32), 8, odd_total, striped=True),
+        "rans_b8_striped": f(lambda: models.RansModel(t256.tolist(), 1 << 8, 8, 32), 256, t256, striped=True),
+        "tans_tablefree_striped": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256, striped=True),
         "tans_tablefree": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256),
         "tans_table": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256, env={"SCL_TANS_KERNELS": "table"}),
         "range_t256": f(lambda: models.RangeModel(t256.tolist(), 32, 32), 256, t256),
@@ -120,16 +126,21 @@ def test_damaged_streams(name, kind, monkeypatch):
         p = freq / freq.sum()
         host_sym = rng.choice(K, size=(n_chunks, row), p=p).astype(sym_np_t)
         sym = torch.from_numpy(host_sym.view(np.int16) if fam["u16"] else host_sym).to(dev)[:, :chunk_len]
-        enc = model.encode_batch(sym, any_parameter_kernels=fam["any_par"])
+        enc = model.encode_batch(sym, any_parameter_kernels=fam["any_par"], layout="striped" if fam["striped"] else None)
         torch.cuda.synchronize()
         assert int(enc.status.abs().sum()) == 0
-        data = enc.data.cpu().numpy().copy()
+        # (striped batches are damaged in their LINEAR view -- what bit_offset indexes -- and striped again below)
+        data = enc.linear_data().cpu().numpy().copy()
         offs, nbits = enc.bit_offset.cpu().numpy(), enc.nbits.cpu().numpy()
         victims = rng.choice(n_chunks, size=max(1, n_chunks // 3), replace=False)
         in_nbits = _damage(kind, rng, data, offs, nbits, victims, enc.stride, chunk_len)
         damaged = np.zeros(n_chunks, dtype=bool)
         damaged[victims] = True
 
+        if fam["striped"]:
+            n64, S = (n_chunks + 63) // 64, enc.stride
+            body = data[: n64 * 64 * S].reshape(n64, 64, S // 16, 16).transpose(0, 2, 1, 3).reshape(-1)
+            data = np.concatenate([body, np.zeros(16, dtype=np.uint8)])
         esz = 2 if fam["u16"] else 1
         out_stride = row + (0 if not fam["any_par"] else 8)  # symbols per row
         arena = Arena(data.size + n_chunks * (out_stride * esz + 64) + 40 * GUARD + (1 << 20), dev)
@@ -139,7 +150,8 @@ def test_damaged_streams(name, kind, monkeypatch):
         d_nbits.copy_(torch.from_numpy(in_nbits.astype(np.int32)))
         sym_out = arena.take(n_chunks * out_stride * esz, sym_t, (n_chunks, out_stride))
         lens_out, used, status = (arena.take(4 * n_chunks, torch.int32) for _ in range(3))
-        dargs = [model._h, d_in.data_ptr(), d_in.numel(), enc.bit_offset.data_ptr(), d_nbits.data_ptr(), n_chunks,
+        dargs = [model._h, d_in.data_ptr(), enc.stride if fam["striped"] else d_in.numel(), enc.bit_offset.data_ptr(),
+                 d_nbits.data_ptr(), n_chunks,
                  sym_out.data_ptr(), out_stride, chunk_len, lens_out.data_ptr(), used.data_ptr(), status.data_ptr()]
         keep = None
         if model._needs_scratch:
@@ -147,7 +159,8 @@ def test_damaged_streams(name, kind, monkeypatch):
             dargs += [keep.data_ptr() if keep is not None else None, nb]
         prev = L.scl_set_any_parameter_kernels(1 if fam["any_par"] else -1)
         try:
-            rc = model._sym_fn("decode_batch")(*dargs, torch.cuda.current_stream(dev).cuda_stream)
+            rc = model._sym_fn("decode_batch_striped" if fam["striped"] else "decode_batch")(
+                *dargs, torch.cuda.current_stream(dev).cuda_stream)
         finally:
             L.scl_set_any_parameter_kernels(prev)
         lib.check(rc, f"{name} decode_batch")
