@@ -600,6 +600,24 @@ def _random_pow2_table(rng, K, m_log2):
     return f.astype(np.uint32)
 
 
+def _also_on_striped_slots(model, d_sym, d_lens, enc, cap, tag):
+    """the same batch on wave-striped slots (ABI 8) where the model is served: same descriptors, same dense and framed
+    bytes as the linear batch `enc` (whose streams the caller has just compared with the oracle's), same decode"""
+    if not model.striped_ok():
+        return
+    st = model.encode_batch(d_sym, lens=d_lens, layout="striped")
+    assert int(st.status.abs().sum()) == 0 and torch.equal(st.nbits, enc.nbits) and torch.equal(st.bit_offset, enc.bit_offset), tag
+    for framed in (False, True):
+        a, ao = models.compact(enc, framed=framed)
+        b, bo = models.compact(st, framed=framed)
+        assert torch.equal(ao, bo) and torch.equal(a[:int(ao[-1])], b[:int(ao[-1])]), (tag, framed)
+    dec, dlens, used, status = model.decode_encoded(st, cap)
+    dec_l, dlens_l, used_l, _ = model.decode_batch(enc.data, enc.bit_offset, enc.nbits, cap)
+    assert int(status.abs().sum()) == 0 and torch.equal(dlens, dlens_l) and torch.equal(used, used_l), tag
+    keep = torch.arange(cap, device=dec.device)[None, :] < dlens[:, None]
+    assert torch.equal(dec * keep, dec_l * keep), tag
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 20))))
 def test_random_models_fast_paths_vs_oracle(seed, dev):
     """Differential test of the tuned kernels (rANS / tANS / range fast paths) on random power-of-two tables:
@@ -635,6 +653,7 @@ def test_random_models_fast_paths_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"{name} K={K} M=2^{m_log2} chunk {c}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} chunk {c}"
+        _also_on_striped_slots(model, d_sym, d_lens, enc, cap, f"{name} K={K} M=2^{m_log2}")
 
 
 @pytest.mark.parametrize("mode", ["fixed", "order1", "iid", "rans", "tans", "range", "rans_total_3000"])
@@ -875,6 +894,7 @@ def test_random_totals_fast_paths_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"{name} M={M} RF={rf} chunk {c}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"{name} M={M} chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"{name} M={M} chunk {c}"
+        _also_on_striped_slots(model, d_sym, d_lens, enc, cap, f"{name} M={M} RF={rf}")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SCL_RANDOM_SEEDS", 10))))
@@ -1025,6 +1045,8 @@ def test_random_models_num_bits_out_vs_oracle(seed, dev):
             assert int(nbits[c]) == rn, f"b={b} K={K} M=2^{m_log2} RF=2^{r} chunk {c} generic={generic}"
             assert np.array_equal(_stream_bits(data, offs[c], nbits[c]), np.unpackbits(rb)[:rn]), f"chunk {c}"
             assert np.array_equal(dec[c, :lens[c]], sym[c, :lens[c]]), f"chunk {c}"
+        if not generic:  # (NUM_BITS_OUT in {4, 8, 16} within their bounds run on the headline kernels: striped too)
+            _also_on_striped_slots(model, d_sym, d_lens, enc, cap, f"b={b} K={K} M=2^{m_log2} RF=2^{r}")
 
 
 @pytest.mark.parametrize("framed", [False, True])

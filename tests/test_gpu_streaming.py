@@ -154,8 +154,8 @@ def test_histogram_u16_equals_get_counts(K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [2, 8])
-def test_bench_two_ranks_on_one_gpu(ranks):
+@pytest.mark.parametrize("ranks,layout", [(2, "auto"), (8, "auto"), (2, "striped")])
+def test_bench_two_ranks_on_one_gpu(ranks, layout):
     """bench.py's N > 1 code path (per-rank shards and seeds, barriers, max-over-ranks timing, rank-0 JSON line, the
     self-validating --gather) run as 2 and as 8 torch.distributed ranks that share cuda:0 and talk over gloo
     (SCL_BENCH_SHARED_GPU=1; RCCL refuses two ranks on one device, and the GPU box has one)."""
@@ -172,7 +172,7 @@ def test_bench_two_ranks_on_one_gpu(ranks):
     env = dict(os.environ, SCL_BENCH_SHARED_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2",
-           "--warmup", "1", "--min-warm-ms", "0", "--chunks", "4096", "--no-cpu-baseline", "--gather"]
+           "--warmup", "1", "--min-warm-ms", "0", "--chunks", "4096", "--no-cpu-baseline", "--gather", "--layout", layout]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -180,6 +180,9 @@ def test_bench_two_ranks_on_one_gpu(ranks):
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["steps"] == 2 and out["scaling"] == "weak" and out["round_trip_verified"]
     assert out["value"] > 0 and out["config"]["chunks_per_gpu"] == 4096
+    # (4096 chunks per rank: auto = linear slots; "striped" forces the wave-striped layout through every rank's shard, the
+    # compaction in front of the gather included)
+    assert out["config"]["slot_layout"] == ("striped" if layout == "striped" else "linear")
     assert out["value_definition"] == "slots" and 0 < out["value_dense"] < out["value"]
     assert out["multi_gpu"]["ranks"] == ranks and out["multi_gpu"]["scaling_efficiency"] > 0
     g = out["gather"]  # configs[4]: encode -> compact -> gather, sequential and as a pipeline of sub-batches
