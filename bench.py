@@ -5,7 +5,9 @@ Metric (BASELINE.json): MB/s encode+decode of 1 GiB i.i.d. bytes with 256-symbol
 (reference defaults NUM_BITS_OUT=1, RANGE_FACTOR=2^16, M=4096), plus achieved HBM GB/s vs peak.
 
 One "step" = one full encode pass + one full decode pass over the per-GPU batch
-(262 144 chunks x 4 KiB = 1 GiB, one wavefront lane per chunk), inputs resident in HBM.
+(262 144 chunks x 4 KiB = 1 GiB, one wavefront lane per chunk), inputs resident in HBM.  The slots of the batch are laid
+out as `--layout` says: auto = wave-striped slots (C ABI 8) for rANS / tANS batches that fill the chip, linear otherwise;
+the same streams at the same logical bit positions either way (`config.slot_layout` names what ran).
 value = (bytes of all ranks * steps) / wall time of the timed region / 1e6, i.e. N / (t_enc + t_dec).
 
     python bench.py                      # 1 GPU, finishes in a few minutes incl. the CPU baselines and other_configs
@@ -25,8 +27,12 @@ no data-path collective); the only communication is the barrier / max-reduction 
 `--gather` additionally times the optional final gather of the compacted streams to rank 0
 (BASELINE.json configs[4]) and reports it separately; it never enters `value`.
 
+The ONE line printed is the COMPACT contract line (< 6 KB: the contract keys, roofline{,_encode,_decode,_dense}, both CPU
+baselines, `summary` last -- round 5's 21.6 KB line left the driver's record unparsed); the full record goes to
+gpurun_out/bench_full.json (`--full-json`), `--full-line` prints it instead.
+
 The default 1-GPU run (no workload flags) also measures BASELINE.json's other single-GPU configurations and attaches them
-as `other_configs` to the same ONE JSON line: configs[1] at its literal size (65 536 chunks), configs[2] (range coder, 1 GiB
+as `other_configs` to the full record (their numbers ride in the line's `summary`): configs[1] at its literal size (65 536 chunks), configs[2] (range coder, 1 GiB
 of uniform bytes), configs[3] (order-1 adaptive arithmetic coder on a Markov-1 source: K = 16 at 1 GiB, K = 256 at 256 MiB)
 -- each with kernel times, `roofline` (frac + PMC traffic where a stamped pass exists) and both CPU baselines.
 `stream_file` (same run, static-model coders): the reference-API FILE path end to end on 256 MiB of the batch -- file I/O,
