@@ -558,7 +558,7 @@ def measure(w, D, wd, steps, warmup, min_warm_ms, with_cpu, with_restatement, wi
     else:
         sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=5000 + rank, device=dev)
     model, coder_params, spec = make_model(w, freq)
-    layout = model.pick_layout(getattr(w, "layout", "auto"), n_chunks) if w.coder in ("rans", "tans") else "linear"
+    layout = model.pick_layout(getattr(w, "layout", "auto"), n_chunks) if w.coder in ("rans", "tans", "range") else "linear"
     kernels = rocprof_kernel_names(w, model, layout)
     if w.sym_pad:
         padded = torch.zeros((n_chunks, chunk_len + w.sym_pad), dtype=torch.uint8, device=dev)

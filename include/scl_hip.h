@@ -313,6 +313,20 @@ int scl_streams_compact_at(const uint8_t *d_in, const uint64_t *d_bit_offset, co
  *   scl_*_kernel_names_striped    scl_*_kernel_names for the striped kernels. */
 int scl_rans_striped_ok(const scl_rans_model *m);
 int scl_tans_striped_ok(const scl_tans_model *m);
+/* the range coder (RangeEncoder.encode_block / RangeDecoder.decode_block, range_coder.py:188-207, :269-317) on the same
+   layout: streams grow front to back, bit_offset[c] = 8*c*out_stride as on linear slots; served: PRECISION = 32 models over
+   uniform bytes (configs[2]) and over tables with totals 256..4096 (what the cooperative line store of the linear kernels
+   cannot help: lanes that are not in lockstep) */
+int scl_range_striped_ok(const scl_range_model *m);
+int scl_range_encode_batch_striped(const scl_range_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                   const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                   uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                   uint32_t *d_out_nbits, uint32_t *d_status, void *stream);
+int scl_range_decode_batch_striped(const scl_range_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                   const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                   uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                   uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                   uint32_t *d_status, void *stream);
 int scl_rans_kernel_names_striped(const scl_rans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
 int scl_tans_kernel_names_striped(const scl_tans_model *m, uint64_t n_chunks, char *enc, char *dec, uint64_t cap);
 int scl_rans_encode_batch_striped(const scl_rans_model *m, const uint8_t *d_sym, uint64_t sym_stride,

@@ -102,6 +102,9 @@ _SIGNATURES = {
     # wave-striped slots (ABI 8): the tuned rANS kernels (and the tANS models they serve) on the interleaved layout
     "scl_rans_striped_ok": (_int, [_vp]),
     "scl_tans_striped_ok": (_int, [_vp]),
+    "scl_range_striped_ok": (_int, [_vp]),
+    "scl_range_encode_batch_striped": (_int, _ENC_BATCH),
+    "scl_range_decode_batch_striped": (_int, _DEC_BATCH),
     "scl_rans_kernel_names_striped": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
     "scl_tans_kernel_names_striped": (_int, [_vp, _u64, C.c_char_p, C.c_char_p, _u64]),
     "scl_rans_encode_batch_striped": (_int, _ENC_BATCH),

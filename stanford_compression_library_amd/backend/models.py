@@ -219,7 +219,7 @@ class _DeviceModel:
     def striped_ok(self) -> bool:
         """do the striped entry points (ABI 8) serve this model?  (rANS / tANS models on the tuned kernels)"""
         fn = getattr(self._L, f"scl_{self._prefix}_striped_ok", None)
-        return bool(fn is not None and self._prefix in ("rans", "tans") and not self.wide and fn(self._h))
+        return bool(fn is not None and self._prefix in ("rans", "tans", "range") and not self.wide and fn(self._h))
 
     def pick_layout(self, layout: Optional[str], n_chunks: int, any_parameter_kernels: bool = False) -> str:
         """``"linear"`` / ``"striped"`` as asked (striped must be served), ``"auto"``: striped for batches that fill the

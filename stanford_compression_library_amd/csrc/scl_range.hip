@@ -270,6 +270,59 @@ extern "C" int scl_range_encode_batch(const scl_range_model *m, const uint8_t *d
     return SCL_OK;
 }
 
+// ---- wave-striped slots (ABI version 8; scl_range_fast.hip: RgOutT, scl_ans_fast_io.h: AnsBitReaderT) ------------------------
+extern "C" int scl_range_striped_ok(const scl_range_model *m) {
+    return (m && m->dev.K <= 256 && range_fast_striped_ok(m)) ? 1 : 0;
+}
+
+extern "C" int scl_range_encode_batch_striped(const scl_range_model *m, const uint8_t *d_sym, uint64_t sym_stride,
+                                              const uint32_t *d_lens, uint32_t chunk_len, uint64_t n_chunks,
+                                              uint8_t *d_out, uint64_t out_stride, uint64_t *d_out_bit_offset,
+                                              uint32_t *d_out_nbits, uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_sym && d_out && d_out_bit_offset && d_out_nbits, "range_encode_batch_striped: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "range_encode_batch_striped")) return rc_dev;
+    SCL_REQUIRE(scl_range_striped_ok(m), "range_encode_batch_striped: this model is not served by the striped kernels");
+    SCL_REQUIRE(!scl_force_generic(), "range_encode_batch_striped: the calling thread keeps the tuned kernels out");
+    SCL_REQUIRE(out_stride % 16 == 0 && out_stride > 0 && out_stride < (1ull << 24) && ((uintptr_t)d_out & 15) == 0,
+                "range_encode_batch_striped: d_out must be 16-byte aligned and out_stride a multiple of 16 below 2^24");
+    if (n_chunks == 0) return SCL_OK;
+    RowRelay relay;  // rows that do not start on 16-byte boundaries are re-laid
+    if (int rc_r = relay.in(d_sym, sym_stride, chunk_len, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (!scl_rows_aligned(d_sym, sym_stride)) {
+        scl_set_error("range_encode_batch_striped: out of device memory re-laying unaligned symbol rows");
+        return SCL_E_ALLOC;
+    }
+    range_fast_encode_launch(m, d_sym, sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_out_bit_offset,
+                             d_out_nbits, d_status, (hipStream_t)stream, true);
+    SCL_HIP_TRY(hipGetLastError());
+    return SCL_OK;
+}
+
+extern "C" int scl_range_decode_batch_striped(const scl_range_model *m, const uint8_t *d_in, uint64_t in_stride,
+                                              const uint64_t *d_bit_offset, const uint32_t *d_in_nbits,
+                                              uint64_t n_chunks, uint8_t *d_out_sym, uint64_t out_stride,
+                                              uint32_t out_cap, uint32_t *d_out_lens, uint32_t *d_consumed,
+                                              uint32_t *d_status, void *stream) {
+    SCL_REQUIRE(m && d_in && d_bit_offset && d_in_nbits && d_out_sym && d_out_lens && d_consumed,
+                "range_decode_batch_striped: null pointer argument");
+    if (int rc_dev = scl_check_device(m->device, "range_decode_batch_striped")) return rc_dev;
+    SCL_REQUIRE(scl_range_striped_ok(m), "range_decode_batch_striped: this model is not served by the striped kernels");
+    SCL_REQUIRE(!scl_force_generic(), "range_decode_batch_striped: the calling thread keeps the tuned kernels out");
+    SCL_REQUIRE(((uintptr_t)d_in & 15) == 0 && in_stride % 16 == 0 && in_stride > 0 && in_stride < (1ull << 24),
+                "range_decode_batch_striped: d_in must be 16-byte aligned and in_stride a multiple of 16 below 2^24");
+    if (n_chunks == 0) return SCL_OK;
+    RowRelay relay;  // output rows the kernels cannot store to go through aligned scratch and are copied back
+    if (int rc_r = relay.out_begin(d_out_sym, out_stride, out_cap, n_chunks, (hipStream_t)stream)) return rc_r;
+    if (!scl_rows_aligned(d_out_sym, out_stride)) {
+        scl_set_error("range_decode_batch_striped: out of device memory re-laying unaligned output rows");
+        return SCL_E_ALLOC;
+    }
+    range_fast_decode_launch(m, d_in, in_stride, d_bit_offset, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap,
+                             d_out_lens, d_consumed, d_status, (hipStream_t)stream, true);
+    SCL_HIP_TRY(hipGetLastError());
+    return relay.out_end(d_out_lens);
+}
+
 extern "C" int scl_range_decode_batch(const scl_range_model *m, const uint8_t *d_in, uint64_t in_size_bytes,
                                       const uint64_t *d_bit_offset, const uint32_t *d_in_nbits, uint64_t n_chunks,
                                       uint8_t *d_out_sym, uint64_t out_stride, uint32_t out_cap, uint32_t *d_out_lens,

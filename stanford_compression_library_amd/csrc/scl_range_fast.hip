@@ -12,6 +12,8 @@
 //           with a Newton-refined v_rcp_f32), then ONE read of a slot -> {c, f, s} table; 128 symbols per store burst.
 #include <vector>
 
+#include <type_traits>
+
 #include "scl_ans_fast_io.h"  // scl_transpose8: the 8 x 8 register transpose behind the cooperative line store
 #include "scl_range_internal.h"
 
@@ -26,6 +28,7 @@
 // encode
 // ---------------------------------------------------------------------------------------------------
 struct RgOut {
+    static constexpr bool STRIPED = false;
     u64 acc;   // pending bytes as a big-endian number in its low cnt bits (the next byte of the stream is the most significant
                // of them; what lies above bit cnt is left-over and never read) -- round 5: the bytes a symbol releases are then
                // simply the high word of (u64)low << sh, no byte swap and no field extraction per symbol
@@ -170,6 +173,114 @@ struct RgOut {
     }
 };
 
+// Round 6: the same byte accumulator over WAVE-STRIPED slots (scl_ans_fast_io.h: byte b of the logical slot of lane l lives
+// at wave_slot + (b / 16) * 1024 + 16 l + b % 16, so piece q of the 64 lanes of a wave is one contiguous kilobyte).  What the
+// cooperative line store above buys only for lanes in lockstep (uniform bytes), this buys for any table: a lane keeps
+// 16-byte pieces, not 128-byte lines, and the WAVE stores the next row when every lane present holds a complete piece (four
+// nested ballots per flush point; AnsBackWriterT has the argument) -- 64 adjacent pieces per store instruction, no transpose,
+// no 64-byte half line held in registers.  A lane holding more than 15 words when it leaves a flush point (32 ring words - the
+// 16 that 16 symbols can complete) stores its own oldest pieces.  Streams grow front to back: rows ascend.
+struct RgOutT {
+    static constexpr bool STRIPED = true;
+    static constexpr u32 ROW = RGE_THREADS * 4;
+    u64 acc;   // as RgOut
+    u32 cnt;
+    u32 ra;    // LDS byte address of the ring word written next
+    u32 fa;    // LDS byte address of the oldest unflushed word (a multiple of four rows | the thread column)
+    u32 pend;  // completed words not yet in memory
+    u32 goff;  // byte offset (from the workgroup's output base) of this lane's next piece
+    u32 goff0, glimit;  // ... of its first piece / the first offset past its last one (the slot's capacity)
+    u32 overflow;
+    u8 *wg_out;
+
+    __device__ __forceinline__ void init(u32 tid, u8 *wg_out_, u32 out_stride) {
+        wg_out = wg_out_;
+        acc = 0;
+        cnt = 0;
+        ra = fa = tid * 4;
+        pend = 0;
+        overflow = 0;
+        goff = goff0 = (tid >> 6) * (out_stride << 6) + ((tid & 63u) << 4);
+        glimit = goff0 + (out_stride >> 4) * 1024u;
+    }
+    __device__ __forceinline__ void put_bytes(char *lds, u32 bytes, u32 nbits) {
+        acc = (acc << nbits) | bytes;
+        cnt += nbits;
+        if (cnt >= 32) {
+            cnt -= 32;
+            *reinterpret_cast<u32 *>(lds + ra) = __builtin_bswap32((u32)(acc >> cnt));
+            ra = (ra + ROW) & (RGE_RING_BYTES - 1);
+            ++pend;
+        }
+    }
+    // piece R (0 = oldest) of the complete ones -> its row; nothing is updated (rows_done)
+    template <u32 R>
+    __device__ __forceinline__ void store_row(char *lds) {
+        const char *r = lds + ((fa + 4u * R * ROW) & (RGE_RING_BYTES - 1));  // (a piece never wraps: four rows, fa a multiple of four)
+        const u32 w0 = *reinterpret_cast<const u32 *>(r), w1 = *reinterpret_cast<const u32 *>(r + ROW);
+        const u32 w2 = *reinterpret_cast<const u32 *>(r + 2 * ROW), w3 = *reinterpret_cast<const u32 *>(r + 3 * ROW);
+        if (goff + 1024u * R < glimit) {
+            typedef u32 u32x4_nt __attribute__((ext_vector_type(4)));
+            const u32x4_nt t = {w0, w1, w2, w3};
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt *>(wg_out + goff + 1024u * R));
+        } else {
+            overflow = 1;
+        }
+    }
+    __device__ __forceinline__ void rows_done(u32 m) {
+        goff += 1024u * m;
+        fa = (fa + 4u * m * ROW) & (RGE_RING_BYTES - 1);
+        pend -= 4u * m;
+    }
+    // call at least every 16 symbols (<= 16 new words)
+    template <bool COOP_UNUSED = false>
+    __device__ __forceinline__ void maybe_flush(char *lds) {
+        const u32 p = pend;
+        const u64 all = __builtin_amdgcn_ballot_w64(true);
+        if (__builtin_amdgcn_ballot_w64(p >= 4u) == all) {
+            store_row<0>(lds);
+            if (__builtin_amdgcn_ballot_w64(p >= 8u) == all) {
+                store_row<1>(lds);
+                if (__builtin_amdgcn_ballot_w64(p >= 12u) == all) {
+                    store_row<2>(lds);
+                    if (__builtin_amdgcn_ballot_w64(p >= 16u) == all) {
+                        store_row<3>(lds);
+                        rows_done(4);
+                    } else {
+                        rows_done(3);
+                    }
+                } else {
+                    rows_done(2);
+                }
+            } else {
+                rows_done(1);
+            }
+        }
+        while (pend > 15u) {
+            store_row<0>(lds);
+            rows_done(1);
+        }
+    }
+    __device__ __forceinline__ u64 finish(char *lds) {  // returns total bytes
+        while (pend >= 4u) {
+            store_row<0>(lds);
+            rows_done(1);
+        }
+        const u32 cnt_bytes = cnt >> 3;
+        const u64 total = (u64)((goff - goff0) >> 10) * 16u + pend * 4u + cnt_bytes;
+        if (goff >= glimit && (pend || cnt_bytes)) overflow = 1;
+        if (overflow) return total;
+        u8 *piece = wg_out + goff;  // the piece that is still filling: pend < 4 words and < 4 bytes, i.e. at most 15 bytes
+        u32 a = fa;
+        for (u32 j = 0; j < pend; ++j) {
+            *reinterpret_cast<u32 *>(piece + 4 * j) = *reinterpret_cast<const u32 *>(lds + a);
+            a = (a + ROW) & (RGE_RING_BYTES - 1);
+        }
+        for (u32 j = 0; j < cnt_bytes; ++j) piece[4 * pend + j] = (u8)(acc >> (cnt - 8 * (j + 1)));
+        return total;
+    }
+};
+
 // range // M (shrink_range, :100): a shift for a power-of-two total (GEN = false, md.m_log2), else exactly as
 // trunc((range + 0.5) * (1 / M)) in binary64 (range < 2^32, M <= 2^12: the error 2^-20 is far below the distance
 // 0.5 / M of (range + 0.5) / M from an integer)
@@ -238,9 +349,9 @@ __device__ __forceinline__ u32 rg_fast_symbol(u32 &low, u32 &range, const uint2 
 // releases a whole word (the bytes (pb, pn) its pair partner still holds go out first, to keep the reference's order of
 // events) and the bytes after a fourth.  Fast-path results are computed unconditionally and overwritten there (branches
 // are what this kernel has too many of: each costs 0.4-1.3 ns per wave, tools/ubench/valu_rate.hip).
-template <int MODE>
+template <int MODE, typename OUT>
 __device__ __forceinline__ void rg_encode_symbol(u32 &low, u32 &range, const uint2 e, const RgDivM &md, u32 &bytes,
-                                                 u32 &nb, u32 &pb, u32 &pn, RgOut &o, char *lds) {
+                                                 u32 &nb, u32 &pb, u32 &pn, OUT &o, char *lds) {
     const u32 r = rg_range_over_m<MODE>(range, md);
     u32 low0, range0;
     if (RG_UNI(MODE)) {  // e.x = the symbol: c r = s (r f), r f < 2^24 (range < 2^32, M / f = 256): one 24-bit multiply-add
@@ -307,8 +418,8 @@ __device__ __forceinline__ uint2 rg_entry(const char *tab, u32 a) {
     return *reinterpret_cast<const uint2 *>(tab + a);
 }
 
-template <int MODE>
-__device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range, RgOut &o, u32 &bad, char *lds,
+template <int MODE, typename OUT>
+__device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range, OUT &o, u32 &bad, char *lds,
                                             const char *tab, const RgDivM &md) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -351,7 +462,8 @@ __device__ __forceinline__ void rg_encode16(const uint4 v, u32 &low, u32 &range,
     o.template maybe_flush<RG_UNI(MODE)>(lds);
 }
 
-template <int MODE>
+// OUT: RgOut (linear slots) or RgOutT (wave-striped slots, ABI 8: `out` then holds round_up(n_chunks, 64) slots)
+template <int MODE, typename OUT = RgOut>
 __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(RangeFastDev P, const u8 *__restrict__ sym,
                                                                           u64 sym_stride,
                                                                           const u32 *__restrict__ lens, u32 chunk_len,
@@ -368,10 +480,14 @@ __global__ void __launch_bounds__(RGE_THREADS, 4) range_encode_fast_kernel(Range
     if (c >= n_chunks) return;
     const u32 n = lens ? lens[c] : chunk_len;
     const u8 *src = sym + c * sym_stride;
-    RgOut o;
-    // whole wave, equally long chunks: every lane reaches every flush point, so the wave can store lines cooperatively
-    const bool coop = __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
-    o.init(threadIdx.x, out + c * out_stride, out_stride, coop);
+    OUT o;
+    if constexpr (OUT::STRIPED) {
+        o.init(threadIdx.x, out + (u64)blockIdx.x * RGE_THREADS * out_stride, (u32)out_stride);
+    } else {
+        // whole wave, equally long chunks: every lane reaches every flush point, so the wave can store lines cooperatively
+        const bool coop = __builtin_amdgcn_ballot_w64(n == (u32)__builtin_amdgcn_readfirstlane((int)n)) == ~0ull;
+        o.init(threadIdx.x, out + c * out_stride, out_stride, coop);
+    }
     o.put_bytes(lds, n, 32);  // DATA_BLOCK_SIZE_BITS = 32 header, :197
     u32 low = 0, range = 0xFFFFFFFFu, bad = 0;
     RgDivM md;
@@ -701,7 +817,9 @@ __device__ __forceinline__ u32 rg_decode_symbol(u32 &low, u32 &range, u32 &state
     return s;
 }
 
-template <int MODE, bool LUT, bool DIV32>
+// STRIPED: the input is in wave-striped slots (RgOutT / AnsBitReaderT); `in_size_bytes` then carries the slot stride and
+// stream c lies in slot c
+template <int MODE, bool LUT, bool DIV32, bool STRIPED = false>
 __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFastDev P, const u8 *__restrict__ in,
                                                                        u64 in_size_bytes,
                                                                        const u64 *__restrict__ bit_off,
@@ -738,8 +856,11 @@ __global__ void __launch_bounds__(RGD_THREADS) range_decode_fast_kernel(RangeFas
     }
     // the rANS decoder's windowless reader (scl_ans_fast_io.h): the 32 bits at the position come straight out of the ring,
     // once per PAIR of symbols; nothing is advanced under a branch
-    AnsBitReaderW<RGD_THREADS> r;
-    r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
+    typename std::conditional<STRIPED, AnsBitReaderT<RGD_THREADS>, AnsBitReaderW<RGD_THREADS>>::type r;
+    if constexpr (STRIPED)
+        r.init(in, in_size_bytes, c, bit_off[c], lds, threadIdx.x);
+    else
+        r.init(in, in_size_bytes, bit_off[c], lds, threadIdx.x);
     u32 n = r.get(lds, 32);
     u32 state = r.get(lds, 32);  // the first four bytes of the body (:289-291)
     out_lens[c] = n;
@@ -847,10 +968,28 @@ int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_
     return SCL_OK;
 }
 
+// the models the striped kernels are instantiated for: uniform bytes (f = 1, M = 256: configs[2]) and tables with totals
+// 256..4096 (a 256-symbol table like T256 among them) -- the modes the headline-sized batches use
+bool range_fast_striped_ok(const scl_range_model *m) {
+    if (!m->fast) return false;
+    if (m->fdev.uni_t == 0) return true;
+    return m->fdev.uni_t == 0xFFFFFFFFu && m->fdev.M >= 256 && m->fdev.M <= 4096;
+}
+
 void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                               u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
-                              u32 *d_status, hipStream_t st) {
+                              u32 *d_status, hipStream_t st, bool striped) {
     const u32 blocks = (u32)((n_chunks + RGE_THREADS - 1) / RGE_THREADS);
+    if (striped) {  // (range_fast_striped_ok holds: the caller checked)
+#define RG_LAUNCH_ENC_T(MODE)                                                                                         \
+    hipLaunchKernelGGL((range_encode_fast_kernel<MODE, RgOutT>), dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym, \
+                       sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
+        if (m->fdev.uni_t == 0) RG_LAUNCH_ENC_T(3);
+        else if (m->fdev.m_log2 != 0xFFFFFFFFu) RG_LAUNCH_ENC_T(4);
+        else RG_LAUNCH_ENC_T(5);
+#undef RG_LAUNCH_ENC_T
+        return;
+    }
 #define RG_LAUNCH_ENC(MODE)                                                                                      \
     hipLaunchKernelGGL(range_encode_fast_kernel<MODE>, dim3(blocks), dim3(RGE_THREADS), 0, st, m->fdev, d_sym,       \
                        sym_stride, d_lens, chunk_len, n_chunks, d_out, out_stride, d_bit_off, d_nbits, d_status)
@@ -866,8 +1005,19 @@ void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym
 
 void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
-                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st) {
+                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st, bool striped) {
     const u32 blocks = (u32)((n_chunks + RGD_THREADS - 1) / RGD_THREADS);
+    if (striped) {  // totals 256..4096: slot table + binary32 quotient (range_fast_striped_ok)
+#define RG_LAUNCH_DEC_T(MODE)                                                                                          \
+    hipLaunchKernelGGL((range_decode_fast_kernel<MODE, true, true, true>), dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, \
+                       d_in, in_size_bytes, d_bit_off, d_in_nbits, n_chunks, d_out_sym, out_stride, out_cap, d_out_lens,   \
+                       d_consumed, d_status)
+        if (m->fdev.uni_t == 0) RG_LAUNCH_DEC_T(3);
+        else if (m->fdev.m_log2 != 0xFFFFFFFFu) RG_LAUNCH_DEC_T(0);
+        else RG_LAUNCH_DEC_T(1);
+#undef RG_LAUNCH_DEC_T
+        return;
+    }
 #define RG_LAUNCH_DEC2(MODE, LUT, DIV32)                                                                          \
     hipLaunchKernelGGL((range_decode_fast_kernel<MODE, LUT, DIV32>), dim3(blocks), dim3(RGD_THREADS), 0, st, m->fdev, \
                        d_in,                                                                                      \

@@ -36,9 +36,12 @@ struct scl_range_model {
 };
 
 int range_fast_build_tables(scl_range_model *m, const u32 *h_freq, const u32 *h_cum);
+// striped: wave-striped slots (RgOutT / AnsBitReaderT; range_fast_striped_ok must hold) -- d_out holds round_up(n_chunks,
+// 64) slots; the decoder's `in_size_bytes` is then the slot stride
+bool range_fast_striped_ok(const scl_range_model *m);
 void range_fast_encode_launch(const scl_range_model *m, const u8 *d_sym, u64 sym_stride, const u32 *d_lens,
                               u32 chunk_len, u64 n_chunks, u8 *d_out, u64 out_stride, u64 *d_bit_off, u32 *d_nbits,
-                              u32 *d_status, hipStream_t st);
+                              u32 *d_status, hipStream_t st, bool striped = false);
 void range_fast_decode_launch(const scl_range_model *m, const u8 *d_in, u64 in_size_bytes, const u64 *d_bit_off,
                               const u32 *d_in_nbits, u64 n_chunks, u8 *d_out_sym, u64 out_stride, u32 out_cap,
-                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st);
+                              u32 *d_out_lens, u32 *d_consumed, u32 *d_status, hipStream_t st, bool striped = false);

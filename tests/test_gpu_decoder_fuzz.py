@@ -59,6 +59,8 @@ def _families():
         "rans_b1_total86_striped": f(lambda: models.RansModel(odd_total.tolist(), 1 << 16, 1, 32), 8, odd_total, striped=True),
         "rans_b8_striped": f(lambda: models.RansModel(t256.tolist(), 1 << 8, 8, 32), 256, t256, striped=True),
         "tans_tablefree_striped": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256, striped=True),
+        "range_t256_striped": f(lambda: models.RangeModel(t256.tolist(), 32, 32), 256, t256, striped=True),
+        "range_uniform1_striped": f(lambda: models.RangeModel([1] * 256, 32, 32), 256, ones, striped=True),
         "tans_tablefree": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256),
         "tans_table": f(lambda: models.TansModel(t256.tolist(), 1, 32), 256, t256, env={"SCL_TANS_KERNELS": "table"}),
         "range_t256": f(lambda: models.RangeModel(t256.tolist(), 32, 32), 256, t256),
