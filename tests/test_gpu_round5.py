@@ -185,14 +185,24 @@ def test_library_names_its_kernels_like_rocprof(dev):
     for tag, fn, model, n in cases:
         enc, dec = names(fn, model, n)
         assert enc.startswith("rans_encode_fast_kernel<AnsBackWriter") and dec.startswith("rans_decode_fast_kernel<")
-        for rnd in ("r05", "r04"):
-            path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_kernel_trace_summary.txt")
+        # (the LINEAR-slot kernels: round 6's traces name the decoder with its fifth template argument, `false`; its
+        # rans_headline family runs on striped slots -- rans_headline_linear is the same batch on these kernels)
+        for rnd, t in (("r06", "rans_headline_linear" if tag == "rans_headline" else tag),):
+            if tag in ("rans_b8", "tans"):  # round 6 profiled these on striped slots: their names are checked below
+                continue
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{t}_kernel_trace_summary.txt")
             if os.path.exists(path):
                 have = _summary_kernels(path)
                 assert enc in have and dec in have, f"{tag}: {enc} / {dec} not in {path}: {have[:4]}"
                 checked += 1
                 break
-    assert checked >= 3
+    assert checked >= 2
+    # the striped-slot kernels (ABI 8) against the round-6 traces of the families profiled on them
+    for tag, fn, model, n in [(c[0], c[1] + "_striped", c[2], c[3]) for c in cases if c[0] != "config2_64Ki"]:
+        enc, dec = names(fn, model, n)
+        assert "AnsBackWriterT<256>" in enc and dec.endswith(", true>")
+        have = _summary_kernels(os.path.join(ROOT, "profiles", f"r06_{tag}_kernel_trace_summary.txt"))
+        assert enc in have and dec in have, f"{tag}: {enc} / {dec} not in the round-6 trace: {have[:4]}"
     # forced any-parameter kernels: the function names
     prev = L.scl_set_any_parameter_kernels(1)
     try:
