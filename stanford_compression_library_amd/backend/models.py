@@ -336,6 +336,8 @@ class _DeviceModel:
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         striped = striped_stride is not None
         assert not (striped and any_parameter_kernels), "striped slots are read by the tuned kernels only"
+        # (a striped reader walks whole wave-slots: the buffer must hold round_up(n_chunks, 64) slots)
+        assert not striped or data.numel() >= (n_chunks + 63) // 64 * 64 * int(striped_stride), "striped buffer too short"
         args = [self._h, data.data_ptr(), int(striped_stride) if striped else data.numel(), bit_offset.data_ptr(),
                 nbits.data_ptr(), n_chunks,
                 sym.data_ptr(), out_stride, int(chunk_cap), lens.data_ptr(), used.data_ptr(), status.data_ptr()]

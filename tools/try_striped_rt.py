@@ -1,5 +1,5 @@
-"""Round-6 experiment: rANS headline ROUND TRIP on wave-striped slots against the shipped linear slots, same box,
-alternating; both decodes verified against the input; the dense compaction of either timed as well."""
+"""Round 6: the headline ROUND TRIP on wave-striped slots against linear slots, same box, alternating; both decodes verified
+against the input; the dense compaction of either timed as well.  CODER=rans|tans|range (T256 table)."""
 import os
 import sys
 
@@ -15,18 +15,15 @@ n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 chunk_len = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = torch.device("cuda:0")
 freq = bench_data.t256_table()
-model = models.RansModel(freq.tolist(), 1 << 16, 1, 32)
+CODER = os.environ.get("CODER", "rans")  # rans | tans | range
+model = {"rans": lambda: models.RansModel(freq.tolist(), 1 << 16, 1, 32), "tans": lambda: models.TansModel(freq.tolist(), 1, 32),
+         "range": lambda: models.RangeModel(freq.tolist(), 32, 32)}[CODER]()
 sym = bench_data.iid_chunks_device(freq, n_chunks, chunk_len, seed=1, device=dev)
-
-
-def mode(striped):
-    pass
 
 
 enc = {False: model.alloc_encoded(n_chunks, chunk_len, dev), True: model.alloc_encoded(n_chunks, chunk_len, dev, layout='striped')}
 dec = model.alloc_decoded(n_chunks, chunk_len, dev)
 for striped in (False, True):
-    mode(striped)
     model.encode_batch(sym, out=enc[striped])
     out = model.decode_encoded(enc[striped], chunk_len, out=dec)
     torch.cuda.synchronize()
@@ -37,7 +34,6 @@ print("round trips verified (linear and striped)")
 
 
 def time_rt(striped, reps=20):
-    mode(striped)
     e = enc[striped]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
     ev[0].record()
