@@ -392,7 +392,13 @@ __global__ void __launch_bounds__(CPS_THREADS) cp_copy_striped(const u8 *__restr
     const u32 k = lane & 7u, i = lane >> 3;
     const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / SCL_WAVE;  // lane group
     const u64 c = g * 8 + k;
-    const bool live = c < n && rec_off[min(c + 1, n)] <= out_capacity;  // caller sees the required size in rec_off[n]
+    bool live = c < n && rec_off[min(c + 1, n)] <= out_capacity;  // caller sees the required size in rec_off[n]
+    // a descriptor that does not lie inside its own logical slot (the contract of the striped entry points) is not followed
+    // out of the buffer: its record is left unwritten
+    if (live) {
+        const u64 rel = bit_off[c] - c * stride * 8;
+        live = rel <= stride * 8 && (u64)nbits[c] <= stride * 8 - rel;
+    }
     // ---- this lane's stream (the eight lanes of a stream compute the same values) -----------------------------------
     i64 k_first = 1, k_last = 0, rowbase = 0;
     u32 sh = 0, o = 0;
