@@ -32,6 +32,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..backend.models import compact, compact_capacity, compact_into, compact_scratch_bytes, framed_index_host
+from ..utils import fileio as _fileio
 
 def _stock_read_codes(data_stream) -> bool:
     from ..core.data_stream import Uint8FileDataStream
@@ -88,9 +89,13 @@ def _read_full(read_piece, n: int):
 
 
 def _fill(fobj, h: np.ndarray, n: int) -> int:
-    """``readinto`` until h[:n] is full or the file ends -> bytes read"""
-    got = 0
+    """``readinto`` until h[:n] is full or the file ends -> bytes read (regular files: several positional reads at once,
+    utils/fileio.py)"""
     view = memoryview(h)
+    got = _fileio.read_into(fobj, view, n)
+    if got is not None:
+        return got
+    got = 0
     while got < n:
         k = fobj.readinto(view[got:n])
         if not k:
@@ -101,8 +106,11 @@ def _fill(fobj, h: np.ndarray, n: int) -> int:
 
 def _fill_from(fobj, h: np.ndarray, start: int) -> int:
     """``readinto`` behind h[:start] until the buffer is full or the file ends -> bytes read"""
-    got = start
     view = memoryview(h)
+    par = _fileio.read_into(fobj, view[start:], h.size - start)
+    if par is not None:
+        return par
+    got = start
     while got < h.size:
         k = fobj.readinto(view[got:])
         if not k:

@@ -388,3 +388,41 @@ def test_blocks_above_16Mi_symbols_decode_by_default(tmp_path, monkeypatch):
     dec.max_block_size = 999
     with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s, pytest.raises(AssertionError, match="max_block_size"):
         dec.decode(r, s)
+
+
+@pytest.mark.parametrize("coder", ["rans", "range"])
+def test_parallel_positional_reads_change_nothing(coder, tmp_path, monkeypatch):
+    """utils/fileio.py: slabs of a regular file are read by several ``os.preadv`` calls at once (round 6).  Same file bytes
+    out of ``encode``, same symbols out of ``decode``, as with the file object's own ``readinto`` -- slab boundaries in the
+    middle of parts, records that cross the decoder's buffers, a last short slab"""
+    from stanford_compression_library_amd.utils import fileio
+
+    backend_lib.require_device()
+    monkeypatch.setattr(_stream_batch, "SLAB_BYTES", 300_000)
+    monkeypatch.setattr(fileio, "MIN_BYTES", 10_000)
+    monkeypatch.setattr(fileio, "_ALIGN", 4096)
+    rng = np.random.default_rng(8)
+    data = rng.choice(256, size=2_345_678, p=np.r_[np.full(128, 0.006), np.full(128, 0.0018125)]).astype(np.uint8)
+    fr = frequencies_from_counts(np.bincount(data, minlength=256), 4096)
+    enc, dec = _coders(coder, fr)
+    src, a, b, out = (os.path.join(tmp_path, n) for n in ("in.bin", "a.bin", "b.bin", "out.bin"))
+    data.tofile(src)
+    calls = []
+    real = fileio.read_into
+
+    def counted(fobj, view, n):
+        got = real(fobj, view, n)
+        calls.append(got)
+        return got
+
+    monkeypatch.setattr(fileio, "read_into", counted)
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(a) as w:
+        enc.encode(s, 1000, w)
+    with EncodedBlockReader(a) as r, Uint8FileDataStream(out, "wb") as s:
+        dec.decode(r, s)
+    assert open(out, "rb").read() == data.tobytes()
+    assert sum(1 for c in calls if c) >= 8, calls  # the positional path really ran, on both sides
+    monkeypatch.setattr(fileio, "read_into", lambda fobj, view, n: None)  # ... and the file object's own readinto
+    with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(b) as w:
+        enc.encode(s, 1000, w)
+    assert open(a, "rb").read() == open(b, "rb").read()

@@ -32,6 +32,9 @@ else:
 reps = int(os.environ.get("REPS", 2))
 te = td = 1e9
 for r in range(reps):   # first repetition warms the library, the allocator and the page cache
+    for stale in (enc_path, out):  # (re-opening an existing file for writing truncates it first: not encode / decode time)
+        if os.path.exists(stale):
+            os.remove(stale)
     t0 = time.perf_counter()
     with Uint8FileDataStream(src, "rb") as s, EncodedBlockWriter(enc_path) as w:
         enc.encode(s, block, w)
