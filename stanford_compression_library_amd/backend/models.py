@@ -225,17 +225,22 @@ class _DeviceModel:
         fn = getattr(self._L, f"scl_{self._prefix}_striped_ok", None)
         return bool(fn is not None and self._prefix in ("rans", "tans", "range") and not self.wide and fn(self._h))
 
-    def pick_layout(self, layout: Optional[str], n_chunks: int, any_parameter_kernels: bool = False) -> str:
+    STRIPED_MAX_STRIDE = (1 << 24) - 16  # the striped kernels address a workgroup's 256 slots with 32-bit offsets
+
+    def pick_layout(self, layout: Optional[str], n_chunks: int, any_parameter_kernels: bool = False,
+                    stride: Optional[int] = None) -> str:
         """``"linear"`` / ``"striped"`` as asked (striped must be served), ``"auto"``: striped for batches that fill the
         chip when the model is served, else linear; ``None`` = linear"""
         if layout in (None, "linear"):
             return "linear"
-        can = self.striped_ok() and not any_parameter_kernels and not _lib.any_parameter_forced()
+        can = (self.striped_ok() and not any_parameter_kernels and not _lib.any_parameter_forced()
+               and (stride is None or int(stride) <= self.STRIPED_MAX_STRIDE))
         if layout == "auto":
             return "striped" if can and n_chunks >= STRIPED_MIN_CHUNKS_BY_CODER.get(self._prefix, STRIPED_MIN_CHUNKS) else "linear"
         assert layout == "striped", f"unknown layout {layout!r}"
         if not can:
-            raise ValueError("layout='striped': this model (or the any-parameter setting) has no striped kernels")
+            raise ValueError("layout='striped': this model (or the any-parameter setting, or a slot stride of 16 MiB and "
+                             "more) has no striped kernels")
         return "striped"
 
     def alloc_encoded(self, n_chunks: int, chunk_len: int, device, out_stride: Optional[int] = None,
@@ -245,7 +250,7 @@ class _DeviceModel:
         import torch
 
         stride = int(out_stride or self.slot_bytes(chunk_len))
-        layout = self.pick_layout(layout, n_chunks)
+        layout = self.pick_layout(layout, n_chunks, stride=stride)
         slots = (n_chunks + 63) // 64 * 64 if layout == "striped" else n_chunks
         return EncodedBatch(torch.empty(slots * stride + 16, dtype=torch.uint8, device=device), stride,
                             torch.empty(n_chunks, dtype=torch.int64, device=device),
@@ -267,7 +272,8 @@ class _DeviceModel:
         # rows that do not start on 16-byte boundaries are re-laid INSIDE the library (RowRelay, csrc/scl_core.hip)
         if out is None:
             out = self.alloc_encoded(n_chunks, chunk_len, dev, out_stride,
-                                     self.pick_layout(layout, n_chunks, any_parameter_kernels))
+                                     self.pick_layout(layout, n_chunks, any_parameter_kernels,
+                                                      stride=int(out_stride or self.slot_bytes(chunk_len))))
         assert out.n_chunks == n_chunks
         striped = out.layout == "striped"
         assert not (striped and any_parameter_kernels), "striped slots are written by the tuned kernels only"
