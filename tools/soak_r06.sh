@@ -5,7 +5,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r06_soak.txt; mkdir -p gpurun_out
 echo "round 6 soak" > $O
-echo "== decoder fuzzing: SCL_FUZZ_SEEDS=${FUZZ:-120} rounds x 22 decoder families x 4 kinds of damage (tests/test_gpu_decoder_fuzz.py)" >> $O
+echo "== decoder fuzzing: SCL_FUZZ_SEEDS=${FUZZ:-120} rounds x 24 decoder families x 4 kinds of damage (tests/test_gpu_decoder_fuzz.py)" >> $O
 SCL_FUZZ_SEEDS=${FUZZ:-120} timeout 3000 python -m pytest tests/test_gpu_decoder_fuzz.py -q -m gpu -n 4 2>&1 | tail -2 >> $O
 echo "== randomised model tests (tests/test_gpu_batch.py tests/test_gpu_wide_alphabets.py -k random; SCL_RANDOM_SEEDS=${SEEDS:-5000})" >> $O
 SCL_RANDOM_SEEDS=${SEEDS:-5000} timeout 3000 python -m pytest tests/test_gpu_batch.py tests/test_gpu_wide_alphabets.py -q -m gpu -k "random" -n 4 2>&1 | tail -2 >> $O
