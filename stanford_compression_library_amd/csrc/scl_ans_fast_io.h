@@ -463,15 +463,15 @@ struct AnsBackWriterS {
 // are interleaved at 16-byte granularity:
 //     byte b of the logical slot of lane l (stride S, stream ending at S)  ->  wave_slot + (b / 16) * 1024 + 16 l + b % 16
 // i.e. the 16-byte piece q of every lane forms ONE contiguous kilobyte ("row" q): eight neighbouring lanes share a
-// 128-byte line.  A lane then stores a piece as soon as it has one (a 16-byte store whose neighbours, a few symbols apart
-// in time, complete the line in L2), buffers 16 bytes instead of 128, and the ring shrinks to 128 bytes per lane: 32 KiB +
-// the 4 KiB table per workgroup = four workgroups per CU, four waves per SIMD.  Nothing is cooperative, so ragged
-// batches and partial waves take the same path.  The logical position of every bit is what it was -- `bit_offset` /
+// 128-byte line.  A lane then owes memory 16-byte pieces, not 128-byte lines: the ring shrinks to 128 bytes per lane, 32 KiB
+// + the 4 KiB table per workgroup = four workgroups per CU, four waves per SIMD -- and the WAVE stores a row (64 adjacent
+// pieces, eight whole lines, one instruction) when every lane holds its piece of it (flush()).  No lane depends on
+// another for correctness, so ragged batches and partial waves take the same path.  The logical position of every bit is what it was -- `bit_offset` /
 // `nbits` keep their meaning -- only the mapping to memory changes (scl_stripe_byte below; the decoder's reader and
 // scl_streams_compact undo it).
 //   * bit window, check(): as AnsBackWriterL (the asm block differs in the ring constants only);
 //   * ring: 32 words per lane, [thread][word], words in MEMORY order inside 16-byte pieces, rotated by 16 * (lane mod 8)
-//     bytes against lockstep tables; flush points 32 symbols apart (<= 13 new words on top of <= 3 pending + 16 to spare);
+//     bytes against lockstep tables; flush points 32 symbols apart (<= 13 new words on top of the <= 18 a lane may keep);
 //   * flush(): the wave stores the next row when every lane holds a complete piece (see the comment there).
 __device__ __forceinline__ u64 scl_stripe_byte(u64 logical_byte, u64 stride) {
     // logical byte address in a batch of slots of `stride` bytes (a multiple of 16) -> physical byte address
